@@ -1,0 +1,201 @@
+"""The CPU oracle against the golden vectors captured from the reference.
+
+These pin the oracle (oracle/mvf_oracle.{c,py}) to the reference's own
+outputs; the GPU parity tests then compare the HIP path with the oracle.
+"""
+import numpy as np
+import pytest
+
+import mvf_oracle as orc
+
+
+def _s(a):
+    return a.item() if a.ndim == 0 else a
+
+
+@pytest.mark.parametrize("name", ["plain", "crop_mask", "scannet", "tiny"])
+def test_camera_projection(golden, name):
+    g = golden("proj_" + name)
+    mask = g["mask"] if g["mask"].size else None
+    idx, dist, x, y = orc.camera_projection(
+        g["xyz"], g["img_xyz"], img_intrinsic_pinhole=g["intrinsic"],
+        img_extrinsic=g["extrinsic"], img_mask=mask, img_size=tuple(g["img_size"]),
+        crop_top=int(g["crop_top"]), crop_bottom=int(g["crop_bottom"]),
+        r_max=float(g["r_max"]), r_min=float(g["r_min"]), camera=str(g["camera"]))
+    assert np.array_equal(idx, g["indices"])
+    assert np.array_equal(dist.view(np.uint32), g["dist"].view(np.uint32))
+    assert np.array_equal(x.view(np.uint64), g["x_proj"].view(np.uint64))
+    assert np.array_equal(y.view(np.uint64), g["y_proj"].view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["nocrop", "crop"])
+def test_splat_and_zbuffer(golden, name):
+    g = golden("vis_" + name)
+    kw = dict(img_size=tuple(g["img_size"]), crop_top=int(g["crop_top"]),
+              crop_bottom=int(g["crop_bottom"]), voxel=float(g["voxel"]),
+              k_swell=float(g["k_swell"]), d_swell=float(g["d_swell"]))
+    splat = orc.pinhole_splat(g["x_proj"], g["y_proj"], g["dist"], g["intrinsic"], **kw)
+    assert np.array_equal(splat, g["splat"])
+    for tag, exact in (("splat", False), ("exact", True)):
+        idx, x, y = orc.visibility_from_splatting(
+            g["x_proj"], g["y_proj"], g["dist"], None,
+            img_intrinsic_pinhole=g["intrinsic"], exact=exact, **kw)
+        assert np.array_equal(idx, g[tag + "_idx"]), tag
+        assert np.array_equal(x, g[tag + "_x"]), tag
+        assert np.array_equal(y, g[tag + "_y"]), tag
+
+
+@pytest.mark.parametrize("name", ["full", "bare"])
+def test_visibility_model(golden, name):
+    from mvfusion import synthetic as S
+    g = golden("model_" + name)
+    nrm, lin, pla, sca = S.surface_normals(g["xyz"])
+    use = bool(g["use_attrs"])
+    out = orc.visibility_model(
+        g["xyz"], g["img_xyz"], method="splatting",
+        linearity=lin if use else None, planarity=pla if use else None,
+        scattering=sca if use else None, normals=nrm if use else None,
+        img_intrinsic_pinhole=g["intrinsic"], img_extrinsic=g["extrinsic"],
+        img_size=tuple(g["img_size"]), crop_top=0, crop_bottom=0, r_max=20, r_min=0,
+        voxel=0.05, k_swell=1.5, d_swell=1e6, exact=True,
+        camera="kitti360_perspective")
+    assert np.array_equal(out["idx"], g["idx"])
+    assert np.array_equal(out["x"], g["x"])
+    assert np.array_equal(out["y"], g["y"])
+    assert np.array_equal(out["depth"], g["depth"])
+    assert out["features"].shape == g["features"].shape
+    np.testing.assert_allclose(out["features"], g["features"], rtol=0, atol=1e-6)
+
+
+def test_depth_map_visibility(golden):
+    g = golden("depth_map")
+    dm = orc.decode_s3dis_depth(g["raw_png"])
+    assert np.array_equal(dm, g["depth_map"])
+    idx, x, y = orc.visibility_from_depth_map(
+        g["x_proj"], g["y_proj"], g["dist"], depth_map=dm,
+        img_size=tuple(g["img_size"]), depth_threshold=float(g["depth_threshold"]))
+    assert np.array_equal(idx, g["indices"])
+    assert np.array_equal(x, g["x"]) and np.array_equal(y, g["y"])
+
+
+def test_lexops(golden):
+    g = golden("lexops")
+    assert np.array_equal(orc.lexargunique(g["a"], g["b"], g["c"]), g["argunique"])
+    assert np.array_equal(orc.lexunique(g["a"]), g["unique_a"])
+    assert orc.lexargunique(g["a"][:0], g["b"][:0]).shape[0] == 0
+    # argsort: unstable in the reference -> equal as sorted sequences
+    mine, theirs = orc.lexargsort(g["a"], g["b"]), g["argsort"]
+    for arr in (g["a"], g["b"]):
+        assert np.array_equal(arr[mine], arr[theirs])
+
+
+def canonical_pixels(view_ptr, pixels):
+    """Sort the pixels of each view group by (x, y): the reference leaves the
+    order inside a (point, image) group unspecified (unstable argsort)."""
+    out = pixels.copy()
+    for a, b in zip(view_ptr[:-1], view_ptr[1:]):
+        if b - a > 1:
+            seg = pixels[a:b]
+            out[a:b] = seg[np.lexsort((seg[:, 1], seg[:, 0]))]
+    return out
+
+
+def test_from_dense(golden):
+    g = golden("from_dense")
+    m = orc.mapping_from_dense(
+        g["point_ids"], g["image_ids"], g["pixels"], g["features"],
+        num_points=int(g["num_points"]))
+    assert np.array_equal(m["pointers"], g["pointers"])
+    assert np.array_equal(m["images"], g["images"])
+    assert np.array_equal(m["view_pointers"], g["view_pointers"])
+    assert np.array_equal(m["pixels"], canonical_pixels(g["view_pointers"], g["out_pixels"]))
+    np.testing.assert_allclose(m["features"], g["out_features"], rtol=1e-6, atol=1e-7)
+
+
+def _cams(g):
+    return dict(pos=g["cam_pos"], extrinsic=g["extrinsic"], fx=g["fx"], fy=g["fy"],
+                mx=g["mx"], my=g["my"])
+
+
+@pytest.mark.parametrize("name", ["mapimages_exact", "mapimages_exact_sphere",
+                                  "mapimages_splat"])
+def test_map_images(golden, name):
+    from mvfusion import synthetic as S
+    g = golden(name)
+    nrm, lin, pla, sca = S.surface_normals(g["xyz"])
+    use = bool(g["use_attrs"])
+    m = orc.map_images(
+        g["xyz"], g["mapping_index"], _cams(g), order=g["order"],
+        ref_size=tuple(g["ref_size"]), proj_upscale=_s(g["proj_upscale"]),
+        downscale=_s(g["downscale"]), crop_size=tuple(g["crop_size"]),
+        crop_offsets=g["crop_offsets"], cylinder=bool(g["cylinder"]),
+        linearity=lin if use else None, planarity=pla if use else None,
+        scattering=sca if use else None, normals=nrm if use else None,
+        voxel=0.05, r_max=20, r_min=0, k_swell=1.5, d_swell=1e6,
+        exact=bool(g["exact"]), camera="kitti360_perspective")
+    assert m["seen_images"].shape[0] == int(g["out_num_views"])
+    assert np.array_equal(m["pointers"], g["pointers"])
+    assert np.array_equal(m["images"], g["images"])
+    assert np.array_equal(m["view_pointers"], g["view_pointers"])
+    assert m["pixels"].dtype == g["pixels"].dtype
+    assert np.array_equal(m["pixels"], canonical_pixels(g["view_pointers"], g["pixels"]))
+    np.testing.assert_allclose(m["features"], g["features"], rtol=0, atol=1e-6)
+
+
+def test_segment_csr(golden):
+    g = golden("segment_csr")
+    for C in ("1", "13", "64", "96", "doc"):
+        for mode in ("max", "mean", "min", "sum"):
+            out = orc.segment_csr(g[f"x_{C}"], g[f"ptr_{C}"], mode)
+            ref = g[f"out_{C}_{mode}"]
+            if mode in ("max", "min"):
+                assert np.array_equal(out, ref), (C, mode)
+            else:
+                np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_segment_softmax(golden):
+    g = golden("segment_softmax")
+    np.testing.assert_allclose(
+        orc.segment_softmax_csr(g["doc_src"], g["doc_ptr"]), g["doc_out"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(
+        orc.segment_softmax_csr(g["doc_src"], g["doc_ptr"], scaling=True),
+        g["doc_out_scaled"], rtol=1e-6, atol=1e-9)
+    for G in (1, 3, 4):
+        x, ptr = g[f"x_{G}"], g[f"ptr_{G}"]
+        np.testing.assert_allclose(
+            orc.segment_softmax_csr(x, ptr), g[f"out_{G}"], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(
+            orc.segment_softmax_csr(x, ptr, scaling=True), g[f"out_{G}_scaled"],
+            rtol=2e-6, atol=1e-9)
+        assert np.array_equal(orc.segment_gather_csr(x, ptr, "max"), g[f"seggather_{G}"])
+        assert np.array_equal(orc.expand_group_feat(x[:50], G, 10), g[f"expand_{G}"])
+
+
+def _sd(g):
+    return {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+
+
+@pytest.mark.parametrize("name", ["qkv_default", "qkv_groups4", "qkv_nogate"])
+def test_qkv_pool(golden, name):
+    g = golden(name)
+    parts = orc.qkv_pool(
+        g["x_main"], g["x_mod"], g["x_map"], g["ptr"], _sd(g),
+        num_groups=int(g["num_groups"]), nc_qk=int(g["nc_qk"]),
+        gating=bool(g["gating"]), dim_scaling=bool(g["dim_scaling"]),
+        group_scaling=bool(g["group_scaling"]), use_num=bool(g["use_num"]),
+        return_parts=True)
+    scale = np.abs(g["x_pool"]).max()
+    np.testing.assert_allclose(parts["C"], g["C"].reshape(parts["C"].shape), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(parts["A"], g["A"].reshape(parts["A"].shape), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(parts["x_pool"], g["x_pool"], rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_group_pool(golden):
+    g = golden("group_pool")
+    out = orc.group_pool(
+        g["x_mod"], g["x_map"], g["ptr"], _sd(g), num_groups=int(g["num_groups"]),
+        gating=bool(g["gating"]), group_scaling=bool(g["group_scaling"]),
+        use_num=bool(g["use_num"]))
+    scale = np.abs(g["x_pool"]).max()
+    np.testing.assert_allclose(out, g["x_pool"], rtol=1e-5, atol=1e-5 * scale)
