@@ -1,0 +1,199 @@
+/*
+ * mvfusion -- C ABI of the MI355X (gfx950) multi-view image->point fusion path.
+ *
+ * The reference implements this path in Python (numba on CPU, torch +
+ * torch_scatter on GPU) and has no FFI of its own: every entry point below
+ * replaces one Python-level function of
+ * DeepViewAgg-Wildscenes/torch_points3d (cited per function) and is bound from
+ * Python with ctypes (multimodal-fusion_amd/mvfusion/_lib.py).
+ *
+ * Conventions
+ *  - Every pointer is a caller-owned DEVICE buffer unless its name starts with
+ *    h_ (host).  Nothing is allocated or freed by the library; temporary
+ *    storage comes from the caller's `workspace` (size from the matching
+ *    *_workspace_bytes query, 256-byte aligned).
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    work is enqueued asynchronously; data-dependent sizes are written to a
+ *    device `counters` array that the caller reads after synchronising.
+ *  - Return value: 0 = ok, negative = error (MVF_E_*); mvf_last_error() gives a
+ *    thread-local message.  No exceptions cross the boundary.
+ *  - Matrices are row-major.  Images are addressed [x][y] (x = column index in
+ *    [0, W), y = row index), the layout of the reference's depth / index maps
+ *    and masks.
+ */
+#ifndef MVFUSION_H
+#define MVFUSION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVF_VERSION 100
+
+enum {
+    MVF_OK = 0,
+    MVF_E_INVALID = -1,    /* bad argument (shape, range, null pointer) */
+    MVF_E_WORKSPACE = -2,  /* workspace too small */
+    MVF_E_LAUNCH = -3      /* HIP launch / runtime error */
+};
+
+enum { MVF_CAM_KITTI360_PERSPECTIVE = 0, MVF_CAM_SCANNET = 1 };
+enum { MVF_REDUCE_SUM = 0, MVF_REDUCE_MEAN = 1, MVF_REDUCE_MIN = 2, MVF_REDUCE_MAX = 3 };
+
+/* One pinhole view.  cam_to_world is the 4x4 extrinsic for
+ * 'kitti360_perspective' and inverse(extrinsic) for 'scannet'
+ * (core/multimodal/visibility.py:232-242). */
+typedef struct {
+    float img_xyz[3];        /* camera centre used for the range test */
+    float fx, fy, cx, cy;    /* intrinsic [0][0], [1][1], [0][2], [1][2] */
+    float cam_to_world[16];
+    double centre[3];        /* float64 camera position: radius sampling of MapImages */
+    int32_t crop_off_x, crop_off_y; /* MapImages: crop offsets of this view */
+} mvf_view;                  /* 128 bytes */
+
+/* Parameters shared by all views of a call (VisibilityModel attributes,
+ * visibility.py:1697-1705,1784-1790,1799-1801). */
+typedef struct {
+    int32_t W, H;            /* projection image size */
+    int32_t crop_top, crop_bottom;
+    int32_t camera;          /* MVF_CAM_* */
+    int32_t exact;           /* SplattingVisibility.exact */
+    double r_max, r_min;
+    double voxel, k_swell, ln_d_swell; /* ln_d_swell = log(d_swell) on the host */
+    float depth_threshold;   /* DepthBasedVisibility */
+    int32_t pad_;
+} mvf_vis_params;
+
+int mvf_version(void);
+const char *mvf_last_error(void);
+
+/* ---------------------------------------------------------------------- *
+ * camera_projection  (visibility.py:478-538,592-623; pinhole cameras)
+ * Keeps points with r_min < dist < r_max that project inside the (cropped)
+ * image, in front of the camera, on a true mask pixel; outputs are compacted
+ * in ascending point index.  Outputs need room for n entries.
+ * counters[0] <- number kept.  mask: [W][H] bytes or NULL.
+ * ---------------------------------------------------------------------- */
+size_t mvf_camera_projection_workspace_bytes(int64_t n);
+int mvf_camera_projection(
+    const float *xyz, int64_t n, const mvf_view *h_view,
+    const mvf_vis_params *h_params, const uint8_t *mask,
+    int64_t *indices, float *dist, double *x_proj, double *y_proj,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * visibility_from_splatting  (visibility.py:1073-1195,1288-1321; pinhole
+ * splats :761-827).  Z-buffer of the m splats; ties in depth go to the lower
+ * index; exact != 0 keeps one entry per seen point at its centre pixel (the
+ * higher index wins a shared pixel).  Output order: ascending x then y.
+ * out_* need room for `out_capacity` entries (m is enough when exact, W*Hc
+ * always is).  counters[0] <- number of mappings, counters[1] <- number of
+ * (splat, tile) pairs the call needed, counters[2] <- 1 if pair_capacity or
+ * out_capacity was exceeded (outputs are then incomplete: call again with
+ * larger buffers).
+ * ---------------------------------------------------------------------- */
+size_t mvf_splat_visibility_workspace_bytes(
+    int64_t m, int32_t W, int32_t H, int64_t pair_capacity);
+int mvf_splat_visibility(
+    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
+    float fx, float fy, const mvf_vis_params *h_params, int64_t pair_capacity,
+    int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * visibility_from_depth_map  (visibility.py:1361-1388) on a decoded [W][H]
+ * float32 map (what read_s3dis_depth_map :1328-1358 returns).  Keeps
+ * |map[int x][int y] - dist| <= depth_threshold, ascending index.
+ * counters[0] <- number kept.
+ * ---------------------------------------------------------------------- */
+size_t mvf_depth_map_visibility_workspace_bytes(int64_t m);
+int mvf_depth_map_visibility(
+    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
+    const float *depth_map, int32_t W, int32_t H, float depth_threshold,
+    int64_t *out_idx, double *out_x, double *out_y, int64_t *counters,
+    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * postprocess_features  (visibility.py:1548-1600): per mapped point
+ * normalised depth, [linearity, planarity, scattering], [|cos| orientation],
+ * pixel height.  idx: point index of each mapping (gathers xyz / attributes);
+ * attribute pointers may be NULL.  out: [k][F] row-major,
+ * F = 2 + #non-NULL attributes.
+ * ---------------------------------------------------------------------- */
+int mvf_mapping_features(
+    const float *xyz, const int64_t *idx, const double *y_proj,
+    const float *dist, int64_t k, const float *h_img_xyz,
+    const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t H, double r_max, double r_min,
+    float *out, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * MapImages._process, exact splat visibility, all V views of one sample in
+ * one launch set (core/data_transform/multimodal/image.py:192-428 with
+ * SplattingVisibility(exact=True), then ImageMapping.from_dense,
+ * core/multimodal/image.py:1738-1805).
+ *
+ * xyz: [N][3] points ALREADY PERMUTED into the sampler's traversal order
+ * (position in this array = local order used for depth ties and centre-pixel
+ * conflicts, transforms.py:332,386); point_ids[i] = mapping id of the point at
+ * position i; they must be distinct values in [0, num_points).
+ * inv_ids: [num_points] position of each id (-1 if absent).
+ * views: [V] device array of mvf_view.  cylinder != 0 tests the sampling
+ * radius (r_max) in the xy plane only.  Attribute arrays follow the permuted
+ * order; NULL = absent.  mask: [W][H] bytes or NULL.
+ * Pixel conversion: pix // proj_upscale - crop offset, kept inside crop_size,
+ * // downscale  (image.py:307-319); integer factors only.
+ *
+ * Outputs: pointers [num_points+1]; images / pixels(int16 [Vw][2]) /
+ * features ([Vw][F]) with room for out_capacity views; view_seen [V] flags.
+ * Since every (point, view) maps to one pixel the nested pixel pointers are
+ * arange(Vw+1) and are not written.
+ * counters[0] <- Vw, [1] <- (splat, tile) pairs needed, [2] <- overflow flag,
+ * [3] <- number of views with at least one mapping.
+ * `centre_ws`: persistent scratch of V*W*Hc uint64, zero-filled ONCE by the
+ * caller and then only passed back with a strictly increasing `epoch` >= 1.
+ * ---------------------------------------------------------------------- */
+size_t mvf_map_images_workspace_bytes(
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points,
+    int64_t pair_capacity);
+int mvf_map_images_exact(
+    const float *xyz, const int64_t *point_ids, const int64_t *inv_ids,
+    int64_t n, int64_t num_points, const mvf_view *views, int32_t V,
+    const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, uint64_t *centre_ws, uint32_t epoch,
+    int64_t pair_capacity, int64_t *pointers, int64_t *images, int16_t *pixels,
+    float *features, int64_t out_capacity, int32_t *view_seen,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * torch_scatter.segment_csr(src, ptr, reduce) on dim 0 of a [rows][C] float32
+ * matrix (modules/multimodal/pooling.py:63 and :289,295,519,525,628,799,819,
+ * 863; core/multimodal/image.py:1777).  out: [nseg][C]; empty segment -> 0;
+ * rows of a segment are folded in order (sum / mean are run-to-run
+ * reproducible).  ptr: int64 [nseg+1], non-decreasing, ptr[nseg] <= rows.
+ * ---------------------------------------------------------------------- */
+int mvf_segment_csr(
+    const float *src, int64_t rows, int32_t C, const int64_t *ptr, int64_t nseg,
+    int32_t reduce, float *out, void *stream);
+
+/* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
+int mvf_gather_csr(
+    const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,
+    float *out, void *stream);
+
+/* segment_softmax_csr (pooling.py:770-822): softmax inside CSR segments of a
+ * [rows][G] matrix, optional division of the centred scores by sqrt(segment
+ * size), eps added to the denominator. */
+int mvf_segment_softmax_csr(
+    const float *src, int32_t G, const int64_t *ptr, int64_t nseg, float eps,
+    int32_t scaling, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVFUSION_H */

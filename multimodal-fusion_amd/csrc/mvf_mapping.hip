@@ -1,0 +1,670 @@
+// Point -> pixel mapping kernels: camera projection, splat z-buffer visibility,
+// depth-map visibility, mapping features, and the fused all-views MapImages
+// path.  gfx950 only.
+//
+// Z-buffer design.  The image is cut into 64x64-pixel tiles.  Splats are
+// binned to the tiles they overlap (count -> scan -> fill, order inside a bin
+// is irrelevant), then one 256-thread workgroup per tile resolves its tile in
+// LDS: each pixel holds a 64-bit key  float_bits(dist) << 32 | local_index  and
+// every splat pixel does an LDS atomicMin.  dist > 0 makes the float bit
+// pattern order preserving, so the minimum key is exactly the reference's
+// sequential rule "strictly closer wins, first index wins a tie"
+// (visibility.py:1148-1162), independent of execution order.  The depth buffer
+// never touches HBM.
+#include "mvf_common.h"
+#include "mvf_scan.h"
+
+namespace mvf {
+
+constexpr u64 ZB_EMPTY = ~0ull;
+
+// ------------------------------------------------------------------------- //
+// camera_projection                                                           //
+// ------------------------------------------------------------------------- //
+struct ProjPred {
+    const float *xyz; mvf_view view; mvf_vis_params P; const uint8_t *mask;
+    __device__ bool operator()(i64 i) const {
+        Proj pr;
+        return project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
+    }
+};
+struct ProjEmit {
+    const float *xyz; mvf_view view; mvf_vis_params P; const uint8_t *mask;
+    i64 *indices; float *dist; double *x; double *y;
+    __device__ void operator()(i64 i, i64 pos) const {
+        Proj pr;
+        project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
+        indices[pos] = i; dist[pos] = pr.dist; x[pos] = (double)pr.x; y[pos] = (double)pr.y;
+    }
+};
+
+// ------------------------------------------------------------------------- //
+// splat sources: where a kernel gets (x, y, dist, fx, fy) of splat i, view v  //
+// ------------------------------------------------------------------------- //
+struct ArraySrc {                      // visibility_from_splatting(x_proj, y_proj, dist)
+    const double *x, *y; const float *dist; float fx, fy; i64 m;
+    __device__ i64 count() const { return m; }
+    __device__ bool get(i64 i, int, const mvf_vis_params &, double &ox, double &oy, float &od,
+                        float &ofx, float &ofy) const {
+        ox = x[i]; oy = y[i]; od = dist[i]; ofx = fx; ofy = fy; return true;
+    }
+};
+
+struct CloudSrc {                      // fused MapImages: project xyz[i] into view v
+    const float *xyz; const mvf_view *views; const uint8_t *mask; i64 n; int cylinder;
+    __device__ i64 count() const { return n; }
+    __device__ bool get(i64 i, int v, const mvf_vis_params &P, double &ox, double &oy, float &od,
+                        float &ofx, float &ofy) const {
+        const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        const mvf_view &view = views[v];
+        // radius sampling of MapImages (image.py:242-245; transforms.py:332,386):
+        // float64 squared distance to the view centre <= r_max^2
+        const double ex = (double)px - view.centre[0], ey = (double)py - view.centre[1];
+        double d2 = ex * ex + ey * ey;
+        if (!cylinder) { const double ez = (double)pz - view.centre[2]; d2 = d2 + ez * ez; }
+        if (!(d2 <= P.r_max * P.r_max)) return false;
+        Proj pr;
+        if (!project_point(px, py, pz, view, P, mask, pr)) return false;
+        ox = (double)pr.x; oy = (double)pr.y; od = pr.dist; ofx = view.fx; ofy = view.fy;
+        return true;
+    }
+};
+
+// ------------------------------------------------------------------------- //
+// binning: count, fill                                                        //
+// ------------------------------------------------------------------------- //
+template <class Src, bool ZERO_SEEN>
+__global__ __launch_bounds__(256) void bin_count_kernel(
+    Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
+    unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= src.count()) return;
+    if (ZERO_SEEN) seen[(size_t)v * seen_stride + i] = 0;
+    double x, y; float d, fx, fy;
+    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
+    const BBox b = splat_bbox(x, y, d, fx, fy, P);
+    const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
+    const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
+    unsigned *tc = tile_count + (size_t)v * tiles_per_view;
+    for (int tx = tx0; tx <= tx1; ++tx)
+        for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&tc[tx * tiles_y + ty], 1u);
+}
+
+template <class Src>
+__global__ __launch_bounds__(256) void bin_fill_kernel(
+    Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
+    const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
+    TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= src.count()) return;
+    double x, y; float d, fx, fy;
+    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
+    const BBox b = splat_bbox(x, y, d, fx, fy, P);
+    const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
+    const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
+    TileEntry e;
+    e.key = depth_key(d, (unsigned)i);
+    e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
+    const size_t tbase = (size_t)v * tiles_per_view;
+    for (int tx = tx0; tx <= tx1; ++tx)
+        for (int ty = ty0; ty <= ty1; ++ty) {
+            const size_t t = tbase + tx * tiles_y + ty;
+            const i64 pos = (i64)tile_off[t] + atomicAdd(&tile_cur[t], 1u);
+            if (pos < pair_capacity) entries[pos] = e;
+            else *overflow = 1;
+        }
+}
+
+// ------------------------------------------------------------------------- //
+// z-buffer of one tile in LDS                                                 //
+// ------------------------------------------------------------------------- //
+// WRITE_IDMAP: store winner + 1 (0 = empty) of every pixel to idmap[v][x][y]
+// (non-exact output).  Otherwise mark seen[v][winner] = 1 (exact mode).
+template <bool WRITE_IDMAP>
+__global__ __launch_bounds__(256) void tile_zbuffer_kernel(
+    const TileEntry *__restrict__ entries, const unsigned *__restrict__ tile_off,
+    i64 pair_capacity, int tiles_y, int tiles_per_view, int W, int Hc,
+    uint8_t *__restrict__ seen, i64 seen_stride, unsigned *__restrict__ idmap)
+{
+    __shared__ u64 zb[TILE * TILE];
+    const unsigned t = blockIdx.x;
+    const int v = t / tiles_per_view;
+    const int lt = t - v * tiles_per_view;
+    const int tx = lt / tiles_y, ty = lt - tx * tiles_y;
+    const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
+    i64 begin = tile_off[t], end = tile_off[t + 1];
+    if (end > pair_capacity) end = pair_capacity;
+    if (begin > end) begin = end;
+    const int tid = threadIdx.x;
+
+    if (begin == end) {
+        if (WRITE_IDMAP) {
+            unsigned *im = idmap + (size_t)v * W * Hc;
+            for (int p = tid; p < TILE * TILE; p += 256) {
+                const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
+                if (gx < W && gy < Hc) im[(size_t)gx * Hc + gy] = 0u;
+            }
+        }
+        return;
+    }
+
+    for (int p = tid; p < TILE * TILE; p += 256) zb[p] = ZB_EMPTY;
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    for (i64 base = begin + (i64)wave * 64; base < end; base += 4 * 64) {
+        const int n = (int)((end - base) < 64 ? (end - base) : 64);
+        unsigned k_lo = 0, k_hi = 0, bx = 0, by = 0;
+        if (lane < n) {
+            const uint4 raw = *(const uint4 *)(entries + base + lane);
+            k_lo = raw.x; k_hi = raw.y; bx = raw.z; by = raw.w;
+        }
+        for (int j = 0; j < n; ++j) {
+            const unsigned s_lo = __builtin_amdgcn_readlane(k_lo, j);
+            const unsigned s_hi = __builtin_amdgcn_readlane(k_hi, j);
+            const unsigned s_bx = __builtin_amdgcn_readlane(bx, j);
+            const unsigned s_by = __builtin_amdgcn_readlane(by, j);
+            const u64 key = ((u64)s_hi << 32) | s_lo;
+            int xa = (int)(s_bx & 0xffffu) - x0, xb = (int)(s_bx >> 16) - x0;
+            int ya = (int)(s_by & 0xffffu) - y0, yb = (int)(s_by >> 16) - y0;
+            xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+            xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
+            const int h = yb - ya;
+            if (h <= 0 || xb <= xa) continue;
+            // lanes cover hh (>= h, power of two) rows x 64/hh columns per step
+            const int hlog = h <= 1 ? 0 : 32 - __clz(h - 1);
+            const int ly = lane & ((1 << hlog) - 1), lx = lane >> hlog;
+            const int step = 64 >> hlog;
+            if (ly < h) {
+                u64 *col = zb + ya + ly;
+                for (int x = xa + lx; x < xb; x += step) atomicMin(&col[x << TILE_LOG], key);
+            }
+        }
+    }
+    __syncthreads();
+
+    if (WRITE_IDMAP) {
+        unsigned *im = idmap + (size_t)v * W * Hc;
+        for (int p = tid; p < TILE * TILE; p += 256) {
+            const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
+            if (gx < W && gy < Hc) {
+                const u64 key = zb[p];
+                im[(size_t)gx * Hc + gy] = key == ZB_EMPTY ? 0u : (unsigned)key + 1u;
+            }
+        }
+    } else {
+        uint8_t *sv = seen + (size_t)v * seen_stride;
+        for (int p = tid; p < TILE * TILE; p += 256) {
+            const u64 key = zb[p];
+            if (key == ZB_EMPTY) continue;
+            const unsigned w = (unsigned)key;
+            // one store per vertical run of the same winner
+            if ((p & (TILE - 1)) != 0) {
+                const u64 up = zb[p - 1];
+                if (up != ZB_EMPTY && (unsigned)up == w) continue;
+            }
+            sv[w] = 1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// exact mode for the single-view API: stamp splat centres of seen points      //
+// ------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void centre_stamp_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, i64 m,
+    const uint8_t *__restrict__ seen, int crop_top, int Hc, unsigned *__restrict__ idmap)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m || !seen[i]) return;
+    const int cx = (int)x[i], cy = (int)y[i] - crop_top;
+    atomicMax(&idmap[(size_t)cx * Hc + cy], (unsigned)i + 1u);   // larger index overwrites
+}
+
+struct IdmapPred {
+    const unsigned *idmap;
+    __device__ bool operator()(i64 p) const { return idmap[p] != 0u; }
+};
+struct IdmapEmit {
+    const unsigned *idmap; int Hc, crop_top; i64 *idx, *x, *y;
+    __device__ void operator()(i64 p, i64 pos) const {
+        const i64 px = p / Hc;
+        idx[pos] = (i64)idmap[p] - 1; x[pos] = px; y[pos] = p - px * Hc + crop_top;
+    }
+};
+
+// ------------------------------------------------------------------------- //
+// depth-map visibility                                                        //
+// ------------------------------------------------------------------------- //
+struct DepthPred {
+    const double *x, *y; const float *dist, *map; int H; float thr;
+    __device__ bool operator()(i64 i) const {
+        const i64 xi = (i64)x[i], yi = (i64)y[i];
+        const float real = map[(size_t)xi * H + yi];
+        return fabsf(__fsub_rn(real, dist[i])) <= thr;
+    }
+};
+struct DepthEmit {
+    const double *x, *y; i64 *oidx; double *ox, *oy;
+    __device__ void operator()(i64 i, i64 pos) const { oidx[pos] = i; ox[pos] = x[i]; oy[pos] = y[i]; }
+};
+
+// ------------------------------------------------------------------------- //
+// mapping features (postprocess_features, visibility.py:1548-1600)            //
+// ------------------------------------------------------------------------- //
+struct FeatArgs {
+    const float *lin, *pla, *sca, *nrm;  // per point, may be null
+    int F, H; float lo, hi;              // r_min, r_max + 1e-4 as float32
+};
+
+__device__ __forceinline__ void write_features(
+    float *__restrict__ o, const FeatArgs &A, i64 pt, float px, float py, float pz,
+    const float *img_xyz, float dist, double y_proj)
+{
+    int c = 0;
+    o[c++] = __fdiv_rn(__fsub_rn(dist, A.lo), A.hi);
+    if (A.lin) o[c++] = A.lin[pt];
+    if (A.pla) o[c++] = A.pla[pt];
+    if (A.sca) o[c++] = A.sca[pt];
+    if (A.nrm) {
+        const float den = __fadd_rn(dist, 1e-4f);
+        const float u0 = __fdiv_rn(__fsub_rn(px, img_xyz[0]), den);
+        const float u1 = __fdiv_rn(__fsub_rn(py, img_xyz[1]), den);
+        const float u2 = __fdiv_rn(__fsub_rn(pz, img_xyz[2]), den);
+        const float a = __fmul_rn(u0, A.nrm[3 * pt]), b = __fmul_rn(u1, A.nrm[3 * pt + 1]),
+                    cc = __fmul_rn(u2, A.nrm[3 * pt + 2]);
+        o[c++] = fabsf(__fadd_rn(__fadd_rn(a, b), cc));
+    }
+    o[c++] = (float)(y_proj / (double)A.H);
+}
+
+struct Float3 { float v[3]; };
+
+__global__ __launch_bounds__(256) void features_kernel(
+    const float *__restrict__ xyz, const i64 *__restrict__ idx, const double *__restrict__ y_proj,
+    const float *__restrict__ dist, i64 k, Float3 img_xyz, FeatArgs A, float *__restrict__ out)
+{
+    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= k) return;
+    const i64 pt = idx[j];
+    write_features(out + (size_t)j * A.F, A, pt, xyz[3 * pt], xyz[3 * pt + 1], xyz[3 * pt + 2],
+                   img_xyz.v, dist[j], y_proj[j]);
+}
+
+// ------------------------------------------------------------------------- //
+// fused MapImages (exact): centre conflicts + CSR assembly                    //
+// ------------------------------------------------------------------------- //
+// After the tile pass seen[v][i] tells which points own a z-buffer pixel.
+// centre_ws[v][x][y] is a persistent 64-bit map: atomicMax of
+// (epoch << 32 | i + 1) keeps, per centre pixel, the highest local index of
+// this call -- the reference's ascending overwrite (visibility.py:1183-1187);
+// entries of earlier calls carry a smaller epoch and always lose.
+__global__ __launch_bounds__(256) void mi_centre_kernel(
+    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
+    u64 *__restrict__ centre_ws, unsigned epoch)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (i >= src.n || !seen[(size_t)v * src.n + i]) return;
+    double x, y; float d, fx, fy;
+    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
+    const int cx = (int)x, cy = (int)y - P.crop_top;
+    atomicMax(&centre_ws[((size_t)v * P.W + cx) * Hc + cy], ((u64)epoch << 32) | (u64)((unsigned)i + 1u));
+}
+
+struct PixelXform { int up, down, crop_w, crop_h; };
+
+// Shared by the count and the fill pass: does point position i keep a mapping
+// in view v, and at which (converted) pixel?  0 = not mapped, 1 = mapped by the
+// visibility model but outside the crop (the view still counts as seen,
+// image.py:289-290,350), 2 = kept.
+__device__ __forceinline__ int mi_survives(
+    const CloudSrc &src, const mvf_vis_params &P, const uint8_t *seen, int Hc,
+    const u64 *centre_ws, unsigned epoch, const PixelXform &X, i64 i, int v,
+    int &px, int &py, float &dist, double &y_proj)
+{
+    if (!seen[(size_t)v * src.n + i]) return 0;
+    double x, y; float fx, fy;
+    if (!src.get(i, v, P, x, y, dist, fx, fy)) return 0;
+    const int cx = (int)x, cy = (int)y;
+    const u64 want = ((u64)epoch << 32) | (u64)((unsigned)i + 1u);
+    if (centre_ws[((size_t)v * P.W + cx) * Hc + (cy - P.crop_top)] != want) return 0;
+    // image.py:307-319 (non-negative operands: floor division == truncation)
+    px = cx / X.up - src.views[v].crop_off_x;
+    py = cy / X.up - src.views[v].crop_off_y;
+    if (px < 0 || py < 0 || px >= X.crop_w || py >= X.crop_h) return 1;
+    px /= X.down; py /= X.down;
+    y_proj = y;
+    return 2;
+}
+
+__global__ __launch_bounds__(256) void mi_point_count_kernel(
+    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
+    const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
+    const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ cnt,
+    int *__restrict__ view_seen)
+{
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= num_points) return;
+    const i64 i = inv_ids[q];
+    unsigned c = 0;
+    if (i >= 0) {
+        for (int v = 0; v < V; ++v) {
+            int px, py; float d; double yp;
+            const int s = mi_survives(src, P, seen, Hc, centre_ws, epoch, X, i, v, px, py, d, yp);
+            if (s) view_seen[v] = 1;
+            if (s == 2) ++c;
+        }
+    }
+    cnt[q] = c;
+}
+
+// rank of each seen view among the seen views (lexunique + bucketize,
+// image.py:392-394); V is small: one wave, serial.
+__global__ void mi_view_rank_kernel(const int *__restrict__ view_seen, int V, int *__restrict__ view_rank,
+                                    i64 *__restrict__ n_seen_out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int r = 0;
+    for (int v = 0; v < V; ++v) { view_rank[v] = r; r += view_seen[v] ? 1 : 0; }
+    *n_seen_out = r;
+}
+
+__global__ __launch_bounds__(256) void mi_fill_kernel(
+    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
+    const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
+    const i64 *__restrict__ inv_ids, i64 num_points, const i64 *__restrict__ pointers,
+    const int *__restrict__ view_rank, FeatArgs A, i64 out_capacity,
+    i64 *__restrict__ images, int16_t *__restrict__ pixels, float *__restrict__ features,
+    i64 *__restrict__ overflow)
+{
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= num_points) return;
+    const i64 i = inv_ids[q];
+    if (i < 0) return;
+    i64 k = pointers[q];
+    if (pointers[q + 1] == k) return;
+    const float px3 = src.xyz[3 * i], py3 = src.xyz[3 * i + 1], pz3 = src.xyz[3 * i + 2];
+    for (int v = 0; v < V; ++v) {
+        int px, py; float d; double yp;
+        if (mi_survives(src, P, seen, Hc, centre_ws, epoch, X, i, v, px, py, d, yp) != 2) continue;
+        if (k < out_capacity) {
+            images[k] = view_rank[v];
+            pixels[2 * k] = (int16_t)px; pixels[2 * k + 1] = (int16_t)py;
+            write_features(features + (size_t)k * A.F, A, i, px3, py3, pz3,
+                           src.views[v].img_xyz, d, yp);
+        } else {
+            *overflow = 1;
+        }
+        ++k;
+    }
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+// =========================================================================== //
+// C ABI                                                                        //
+// =========================================================================== //
+
+static int check_params(const mvf_vis_params *P, const char *who)
+{
+    MVF_REQUIRE(P != nullptr, "%s: null params", who);
+    MVF_REQUIRE(P->W >= 1 && P->H >= 1 && P->W <= 65535 && P->H <= 65535,
+                "%s: image size %dx%d out of range", who, P->W, P->H);
+    MVF_REQUIRE(P->crop_top >= 0 && P->crop_bottom >= 0 && P->crop_top + P->crop_bottom < P->H,
+                "%s: crops %d+%d do not fit height %d", who, P->crop_top, P->crop_bottom, P->H);
+    MVF_REQUIRE(P->camera == MVF_CAM_KITTI360_PERSPECTIVE || P->camera == MVF_CAM_SCANNET,
+                "%s: unknown camera %d", who, P->camera);
+    return MVF_OK;
+}
+
+extern "C" size_t mvf_camera_projection_workspace_bytes(int64_t n)
+{
+    return align_up(compact_workspace_elems(n) * sizeof(unsigned));
+}
+
+extern "C" int mvf_camera_projection(
+    const float *xyz, int64_t n, const mvf_view *h_view, const mvf_vis_params *h_params,
+    const uint8_t *mask, int64_t *indices, float *dist, double *x_proj, double *y_proj,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_params(h_params, "camera_projection")) return rc;
+    MVF_REQUIRE(n >= 0 && h_view && counters, "camera_projection: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { MVF_HIP(hipMemsetAsync(counters, 0, sizeof(int64_t), st)); return MVF_OK; }
+    MVF_REQUIRE(xyz && indices && dist && x_proj && y_proj, "camera_projection: null buffer");
+    Arena ar(workspace, workspace_bytes);
+    unsigned *blocks = ar.take<unsigned>(compact_workspace_elems(n));
+    if (!ar.ok()) { set_error("camera_projection: workspace too small"); return MVF_E_WORKSPACE; }
+    ProjPred pred{xyz, *h_view, *h_params, mask};
+    ProjEmit emit{xyz, *h_view, *h_params, mask, (i64 *)indices, dist, x_proj, y_proj};
+    compact(pred, emit, (i64)n, blocks, (i64 *)counters, (i64)n, (i64 *)nullptr, st);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+static inline void tile_grid(const mvf_vis_params &P, int &tiles_x, int &tiles_y, int &Hc)
+{
+    Hc = P.H - P.crop_top - P.crop_bottom;
+    tiles_x = (P.W + TILE - 1) / TILE;
+    tiles_y = (Hc + TILE - 1) / TILE;
+}
+
+extern "C" size_t mvf_splat_visibility_workspace_bytes(
+    int64_t m, int32_t W, int32_t H, int64_t pair_capacity)
+{
+    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t npix = (size_t)W * H;
+    size_t b = 0;
+    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;                // count, off, cur
+    b += align_up(scan_workspace_elems(tiles) * sizeof(unsigned));
+    b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
+    b += align_up((size_t)(m > 0 ? m : 1));                           // seen
+    b += align_up(npix * sizeof(unsigned));                           // idmap
+    b += align_up(compact_workspace_elems(npix) * sizeof(unsigned));
+    return b;
+}
+
+extern "C" int mvf_splat_visibility(
+    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
+    float fx, float fy, const mvf_vis_params *h_params, int64_t pair_capacity,
+    int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_params(h_params, "splat_visibility")) return rc;
+    MVF_REQUIRE(m >= 1 && m < (1ll << 32), "splat_visibility: m=%lld out of range", (long long)m);
+    MVF_REQUIRE(x_proj && y_proj && dist && out_idx && out_x && out_y && counters,
+                "splat_visibility: null buffer");
+    MVF_REQUIRE(pair_capacity >= 1 && out_capacity >= 0, "splat_visibility: bad capacity");
+    const mvf_vis_params P = *h_params;
+    hipStream_t st = (hipStream_t)stream;
+    int tiles_x, tiles_y, Hc;
+    tile_grid(P, tiles_x, tiles_y, Hc);
+    const i64 tiles = (i64)tiles_x * tiles_y;
+    const i64 npix = (i64)P.W * Hc;
+
+    Arena ar(workspace, workspace_bytes);
+    unsigned *tile_count = ar.take<unsigned>(tiles + 1);
+    unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
+    unsigned *tile_off = ar.take<unsigned>(tiles + 1);
+    unsigned *scan_ws = ar.take<unsigned>(scan_workspace_elems(tiles));
+    TileEntry *entries = ar.take<TileEntry>(pair_capacity);
+    uint8_t *seen = ar.take<uint8_t>(m);
+    unsigned *idmap = ar.take<unsigned>(npix);
+    unsigned *cblocks = ar.take<unsigned>(compact_workspace_elems(npix));
+    if (!ar.ok()) { set_error("splat_visibility: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
+
+    // tile_count and tile_cur are adjacent: one memset; counters too
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
+    MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
+    if (P.exact) {
+        MVF_HIP(hipMemsetAsync(seen, 0, (size_t)m, st));
+        MVF_HIP(hipMemsetAsync(idmap, 0, (size_t)npix * sizeof(unsigned), st));
+    }
+
+    ArraySrc src{x_proj, y_proj, dist, fx, fy, (i64)m};
+    dim3 grid_m(cdiv(m, 256), 1), block(256);
+    hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false>), grid_m, block, 0, st, src, P, tiles_y,
+                       (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0);
+    exclusive_scan<unsigned, unsigned, i64>(tile_count, tiles, tile_off, scan_ws, (i64 *)counters + 1, st);
+    hipLaunchKernelGGL((bin_fill_kernel<ArraySrc>), grid_m, block, 0, st, src, P, tiles_y, (int)tiles,
+                       tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
+    if (P.exact) {
+        hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
+                           tile_off, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc, seen, (i64)m,
+                           (unsigned *)nullptr);
+        hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
+                           P.crop_top, Hc, idmap);
+    } else {
+        hipLaunchKernelGGL((tile_zbuffer_kernel<true>), dim3((unsigned)tiles), block, 0, st, entries,
+                           tile_off, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
+                           (uint8_t *)nullptr, (i64)0, idmap);
+    }
+    IdmapPred pred{idmap};
+    IdmapEmit emit{idmap, Hc, P.crop_top, (i64 *)out_idx, (i64 *)out_x, (i64 *)out_y};
+    compact(pred, emit, npix, cblocks, (i64 *)counters, (i64)out_capacity, (i64 *)counters + 2, st);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" size_t mvf_depth_map_visibility_workspace_bytes(int64_t m)
+{
+    return align_up(compact_workspace_elems(m) * sizeof(unsigned));
+}
+
+extern "C" int mvf_depth_map_visibility(
+    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
+    const float *depth_map, int32_t W, int32_t H, float depth_threshold,
+    int64_t *out_idx, double *out_x, double *out_y, int64_t *counters,
+    void *workspace, size_t workspace_bytes, void *stream)
+{
+    MVF_REQUIRE(m >= 1 && W >= 1 && H >= 1, "depth_map_visibility: bad shape");
+    MVF_REQUIRE(x_proj && y_proj && dist && depth_map && out_idx && out_x && out_y && counters,
+                "depth_map_visibility: null buffer");
+    Arena ar(workspace, workspace_bytes);
+    unsigned *blocks = ar.take<unsigned>(compact_workspace_elems(m));
+    if (!ar.ok()) { set_error("depth_map_visibility: workspace too small"); return MVF_E_WORKSPACE; }
+    DepthPred pred{x_proj, y_proj, dist, depth_map, H, depth_threshold};
+    DepthEmit emit{x_proj, y_proj, (i64 *)out_idx, out_x, out_y};
+    compact(pred, emit, (i64)m, blocks, (i64 *)counters, (i64)m, (i64 *)nullptr, (hipStream_t)stream);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+static FeatArgs feat_args(const float *lin, const float *pla, const float *sca, const float *nrm,
+                          int H, double r_max, double r_min)
+{
+    FeatArgs A;
+    A.lin = lin; A.pla = pla; A.sca = sca; A.nrm = nrm;
+    A.F = 2 + (lin != nullptr) + (pla != nullptr) + (sca != nullptr) + (nrm != nullptr);
+    A.H = H; A.lo = (float)r_min; A.hi = (float)(r_max + 1e-4);
+    return A;
+}
+
+extern "C" int mvf_mapping_features(
+    const float *xyz, const int64_t *idx, const double *y_proj, const float *dist, int64_t k,
+    const float *h_img_xyz, const float *linearity, const float *planarity,
+    const float *scattering, const float *normals, int32_t H, double r_max, double r_min,
+    float *out, void *stream)
+{
+    MVF_REQUIRE(k >= 0 && H >= 1 && h_img_xyz, "mapping_features: bad arguments");
+    if (k == 0) return MVF_OK;
+    MVF_REQUIRE(xyz && idx && y_proj && dist && out, "mapping_features: null buffer");
+    Float3 c{{h_img_xyz[0], h_img_xyz[1], h_img_xyz[2]}};
+    hipLaunchKernelGGL(features_kernel, dim3(cdiv(k, 256)), dim3(256), 0, (hipStream_t)stream, xyz,
+                       (const i64 *)idx, y_proj, dist, (i64)k, c,
+                       feat_args(linearity, planarity, scattering, normals, H, r_max, r_min), out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" size_t mvf_map_images_workspace_bytes(
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
+{
+    const size_t tiles = (size_t)V * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    size_t b = 0;
+    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;
+    b += align_up(scan_workspace_elems(tiles) * sizeof(unsigned));
+    b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
+    b += align_up((size_t)V * (size_t)(n > 0 ? n : 1));                          // seen
+    b += align_up((size_t)(num_points + 1) * sizeof(unsigned));                  // cnt
+    b += align_up(scan_workspace_elems(num_points) * sizeof(i64));
+    b += align_up((size_t)V * sizeof(int)) * 1;                                  // view_rank
+    return b;
+}
+
+extern "C" int mvf_map_images_exact(
+    const float *xyz, const int64_t *point_ids, const int64_t *inv_ids, int64_t n,
+    int64_t num_points, const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
+    int32_t cylinder, const uint8_t *mask, const float *linearity, const float *planarity,
+    const float *scattering, const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, uint64_t *centre_ws, uint32_t epoch, int64_t pair_capacity,
+    int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    (void)point_ids;
+    if (int rc = check_params(h_params, "map_images_exact")) return rc;
+    MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= 65535,
+                "map_images_exact: bad sizes n=%lld V=%d", (long long)n, V);
+    MVF_REQUIRE(xyz && inv_ids && views && centre_ws && pointers && images && pixels && features &&
+                view_seen && counters, "map_images_exact: null buffer");
+    MVF_REQUIRE(epoch >= 1 && proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 &&
+                pair_capacity >= 1 && out_capacity >= 0, "map_images_exact: bad scalar argument");
+    MVF_REQUIRE(h_params->exact, "map_images_exact: params.exact must be set");
+    const mvf_vis_params P = *h_params;
+    hipStream_t st = (hipStream_t)stream;
+    int tiles_x, tiles_y, Hc;
+    tile_grid(P, tiles_x, tiles_y, Hc);
+    const int tiles_per_view = tiles_x * tiles_y;
+    const i64 tiles = (i64)tiles_per_view * V;
+
+    Arena ar(workspace, workspace_bytes);
+    unsigned *tile_count = ar.take<unsigned>(tiles + 1);
+    unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
+    unsigned *tile_off = ar.take<unsigned>(tiles + 1);
+    unsigned *scan_ws = ar.take<unsigned>(scan_workspace_elems(tiles));
+    TileEntry *entries = ar.take<TileEntry>(pair_capacity);
+    uint8_t *seen = ar.take<uint8_t>((size_t)V * n);
+    unsigned *cnt = ar.take<unsigned>(num_points + 1);
+    i64 *scan_ws64 = ar.take<i64>(scan_workspace_elems(num_points));
+    int *view_rank = ar.take<int>(V);
+    if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
+
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
+    MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
+    MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int), st));
+
+    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
+    dim3 grid_nv(cdiv(n, 256), V), block(256);
+    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true>), grid_nv, block, 0, st, src, P, tiles_y,
+                       tiles_per_view, tile_count, seen, (i64)n);
+    exclusive_scan<unsigned, unsigned, i64>(tile_count, tiles, tile_off, scan_ws, (i64 *)counters + 1, st);
+    hipLaunchKernelGGL((bin_fill_kernel<CloudSrc>), grid_nv, block, 0, st, src, P, tiles_y,
+                       tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
+                       (i64 *)counters + 2);
+    hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
+                       tile_off, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc, seen, (i64)n,
+                       (unsigned *)nullptr);
+    hipLaunchKernelGGL(mi_centre_kernel, grid_nv, block, 0, st, src, P, seen, Hc, (u64 *)centre_ws, epoch);
+
+    PixelXform X{proj_upscale, downscale, crop_w, crop_h};
+    dim3 grid_q(cdiv(num_points, 256));
+    hipLaunchKernelGGL(mi_point_count_kernel, grid_q, block, 0, st, src, P, seen, Hc,
+                       (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points, cnt,
+                       view_seen);
+    exclusive_scan<unsigned, i64, i64>(cnt, num_points, (i64 *)pointers, scan_ws64, (i64 *)counters, st);
+    hipLaunchKernelGGL(mi_view_rank_kernel, dim3(1), dim3(64), 0, st, view_seen, V, view_rank,
+                       (i64 *)counters + 3);
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, 0, st, src, P, seen, Hc, (const u64 *)centre_ws,
+                       epoch, X, V, (const i64 *)inv_ids, (i64)num_points, (const i64 *)pointers,
+                       view_rank, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
+                       (i64)out_capacity, (i64 *)images, pixels, features, (i64 *)counters + 2);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}

@@ -1,0 +1,197 @@
+// CSR segment kernels: the HIP replacement of torch_scatter.segment_csr and of
+// the gather / softmax helpers of modules/multimodal/pooling.py.
+//
+// Layout: src is [rows][C] float32 row-major, ptr is int64 [nseg+1].  A group
+// of LPR lanes (a power of two <= 64, chosen on the host so that one group
+// covers one row with VEC floats per lane) owns one segment and folds its rows
+// in order: sums are therefore identical from run to run and identical to a
+// sequential CPU fold.  Consecutive groups own consecutive segments, so a
+// wavefront reads a contiguous span of rows; HBM-bound: rows*C*4 bytes read
+// once, nseg*C*4 bytes written once.
+#include "mvf_common.h"
+
+namespace mvf {
+
+template <int VEC> struct Vec;
+template <> struct Vec<1> { typedef float T; };
+template <> struct Vec<4> { typedef float4 T; };
+
+template <int MODE> __device__ __forceinline__ float fold(float a, float x)
+{
+    if (MODE == MVF_REDUCE_MAX) return x > a ? x : a;
+    if (MODE == MVF_REDUCE_MIN) return x < a ? x : a;
+    return __fadd_rn(a, x);
+}
+
+template <int MODE> __device__ __forceinline__ void fold_v(float &a, const float &x) { a = fold<MODE>(a, x); }
+template <int MODE> __device__ __forceinline__ void fold_v(float4 &a, const float4 &x)
+{
+    a.x = fold<MODE>(a.x, x.x); a.y = fold<MODE>(a.y, x.y);
+    a.z = fold<MODE>(a.z, x.z); a.w = fold<MODE>(a.w, x.w);
+}
+__device__ __forceinline__ void scale_v(float &a, float c) { a = __fdiv_rn(a, c); }
+__device__ __forceinline__ void scale_v(float4 &a, float c)
+{
+    a.x = __fdiv_rn(a.x, c); a.y = __fdiv_rn(a.y, c); a.z = __fdiv_rn(a.z, c); a.w = __fdiv_rn(a.w, c);
+}
+__device__ __forceinline__ void zero_v(float &a) { a = 0.f; }
+__device__ __forceinline__ void zero_v(float4 &a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void segment_csr_kernel(
+    const float *__restrict__ src, int C, const i64 *__restrict__ ptr, i64 nseg,
+    int lpr_log, float *__restrict__ out)
+{
+    typedef typename Vec<VEC>::T V;
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 seg = gtid >> lpr_log;
+    if (seg >= nseg) return;
+    const int lig = (int)(gtid & ((1 << lpr_log) - 1));
+    const i64 a = ptr[seg], b = ptr[seg + 1];
+    const int cv = C / VEC;              // row length in vectors
+    const V *s = (const V *)src;
+    V *o = (V *)out;
+    for (int c = lig; c < cv; c += (1 << lpr_log)) {
+        V acc;
+        if (b > a) {
+            const V *p = s + (size_t)a * cv + c;
+            acc = p[0];
+            i64 r = a + 1;
+            // 4 independent loads in flight, folded in row order
+            for (; r + 4 <= b; r += 4) {
+                const V *q = s + (size_t)r * cv + c;
+                const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
+                fold_v<MODE>(acc, x0); fold_v<MODE>(acc, x1);
+                fold_v<MODE>(acc, x2); fold_v<MODE>(acc, x3);
+            }
+            for (; r < b; ++r) fold_v<MODE>(acc, s[(size_t)r * cv + c]);
+            if (MODE == MVF_REDUCE_MEAN) scale_v(acc, (float)(b - a));
+        } else {
+            zero_v(acc);
+        }
+        o[(size_t)seg * cv + c] = acc;
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_csr_kernel(
+    const float *__restrict__ src, int C, const i64 *__restrict__ ptr, i64 nseg,
+    int lpr_log, float *__restrict__ out)
+{
+    typedef typename Vec<VEC>::T V;
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 seg = gtid >> lpr_log;
+    if (seg >= nseg) return;
+    const int lig = (int)(gtid & ((1 << lpr_log) - 1));
+    const i64 a = ptr[seg], b = ptr[seg + 1];
+    const int cv = C / VEC;
+    const V *s = (const V *)src;
+    V *o = (V *)out;
+    for (int c = lig; c < cv; c += (1 << lpr_log)) {
+        const V val = s[(size_t)seg * cv + c];
+        for (i64 r = a; r < b; ++r) o[(size_t)r * cv + c] = val;
+    }
+}
+
+// One thread per (segment, group column): segments are short (<= number of
+// views), the three sweeps stay in L1/L2.
+__global__ __launch_bounds__(256) void segment_softmax_kernel(
+    const float *__restrict__ src, int G, const i64 *__restrict__ ptr, i64 nseg,
+    float eps, int scaling, float *__restrict__ out)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 seg = t / G;
+    if (seg >= nseg) return;
+    const int g = (int)(t - seg * G);
+    const i64 a = ptr[seg], b = ptr[seg + 1];
+    if (b <= a) return;
+    float mx = src[(size_t)a * G + g];
+    for (i64 r = a + 1; r < b; ++r) { const float v = src[(size_t)r * G + g]; mx = v > mx ? v : mx; }
+    const float sq = sqrtf((float)(b - a));
+    float sum = 0.f;
+    for (i64 r = a; r < b; ++r) {
+        float c = __fsub_rn(src[(size_t)r * G + g], mx);
+        if (scaling) c = __fdiv_rn(c, sq);
+        const float e = expf(c);
+        out[(size_t)r * G + g] = e;
+        sum = (r == a) ? e : __fadd_rn(sum, e);
+    }
+    sum = __fadd_rn(sum, eps);
+    for (i64 r = a; r < b; ++r) out[(size_t)r * G + g] = __fdiv_rn(out[(size_t)r * G + g], sum);
+}
+
+static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr_log)
+{
+    vec = (C % 4 == 0 && ((uintptr_t)p0 % 16 == 0) && ((uintptr_t)p1 % 16 == 0)) ? 4 : 1;
+    int lanes = C / vec, l = 0;
+    while ((1 << l) < lanes && l < 6) ++l;
+    lpr_log = l;
+    return 0;
+}
+
+}  // namespace mvf
+
+using namespace mvf;
+
+extern "C" int mvf_segment_csr(
+    const float *src, int64_t rows, int32_t C, const int64_t *ptr, int64_t nseg,
+    int32_t reduce, float *out, void *stream)
+{
+    MVF_REQUIRE(C >= 1 && nseg >= 0 && rows >= 0, "segment_csr: bad shape C=%d nseg=%lld", C, (long long)nseg);
+    MVF_REQUIRE(reduce >= 0 && reduce <= 3, "segment_csr: unknown reduce %d", reduce);
+    if (nseg == 0) return MVF_OK;
+    MVF_REQUIRE(ptr && out && (src || rows == 0), "segment_csr: null pointer");
+    int vec, lpr_log;
+    pick_layout(src, out, C, vec, lpr_log);
+    const i64 threads = nseg << lpr_log;
+    dim3 grid(cdiv(threads, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MVF_SEG(V_, M_) \
+    hipLaunchKernelGGL((segment_csr_kernel<V_, M_>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, lpr_log, out)
+#define MVF_SEG_MODE(V_)                                        \
+    switch (reduce) {                                           \
+    case MVF_REDUCE_SUM: MVF_SEG(V_, MVF_REDUCE_SUM); break;    \
+    case MVF_REDUCE_MEAN: MVF_SEG(V_, MVF_REDUCE_MEAN); break;  \
+    case MVF_REDUCE_MIN: MVF_SEG(V_, MVF_REDUCE_MIN); break;    \
+    default: MVF_SEG(V_, MVF_REDUCE_MAX); break;                \
+    }
+    if (vec == 4) { MVF_SEG_MODE(4) } else { MVF_SEG_MODE(1) }
+#undef MVF_SEG_MODE
+#undef MVF_SEG
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_gather_csr(
+    const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,
+    float *out, void *stream)
+{
+    MVF_REQUIRE(C >= 1 && nseg >= 0 && rows >= 0, "gather_csr: bad shape");
+    if (nseg == 0 || rows == 0) return MVF_OK;
+    MVF_REQUIRE(src && ptr && out, "gather_csr: null pointer");
+    int vec, lpr_log;
+    pick_layout(src, out, C, vec, lpr_log);
+    const i64 threads = nseg << lpr_log;
+    dim3 grid(cdiv(threads, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec == 4)
+        hipLaunchKernelGGL((gather_csr_kernel<4>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, lpr_log, out);
+    else
+        hipLaunchKernelGGL((gather_csr_kernel<1>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, lpr_log, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_segment_softmax_csr(
+    const float *src, int32_t G, const int64_t *ptr, int64_t nseg, float eps,
+    int32_t scaling, float *out, void *stream)
+{
+    MVF_REQUIRE(G >= 1 && nseg >= 0, "segment_softmax_csr: bad shape");
+    if (nseg == 0) return MVF_OK;
+    MVF_REQUIRE(src && ptr && out, "segment_softmax_csr: null pointer");
+    const i64 threads = nseg * G;
+    hipLaunchKernelGGL(segment_softmax_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
+                       (hipStream_t)stream, src, G, (const i64 *)ptr, (i64)nseg, eps, scaling, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}

@@ -1,0 +1,191 @@
+"""``ImageMapping``: the point -> view -> pixel nested CSR produced by
+``MapImages`` and consumed by the pools, with the interface of
+``torch_points3d/core/multimodal/image.py:1717-1909``.
+
+Layout (all on one device):
+``pointers`` int64 [N+1] point -> views; ``values[0]`` = ``images`` int64 [Vw];
+``values[1]`` = CSRData{``pointers`` int64 [Vw+1] view -> pixels, ``values[0]`` =
+``pixels`` [P, 2] (x, y)}; ``values[2]`` = ``features`` float32 [Vw, F].
+"""
+import torch
+
+from .csr import CSRData, CSRBatch
+from . import pooling as _pooling
+
+
+def composite_key(*cols):
+    """Lexicographic composite of non-negative int64 columns
+    (CompositeTensor, utils/multimodal.py:97-153)."""
+    cols = [c.to(torch.int64) for c in cols]
+    if cols[0].shape[0] == 0:
+        return cols[0].clone()
+    maxes = [int(c.abs().max()) + 1 for c in cols]
+    total = 1
+    for m in maxes:
+        total *= m
+    assert total < torch.iinfo(torch.int64).max, \
+        'The dtype of at least one of the input tensors must allow the ' \
+        'composite computation.'
+    key = torch.zeros_like(cols[0])
+    for i, c in enumerate(cols):
+        base = 1
+        for m in maxes[i + 1:]:
+            base *= m
+        key = key + c * base
+    return key
+
+
+def lexargsort(*cols):
+    """Indices sorting the columns lexicographically.  Ties keep their input
+    order (the reference's sort is unstable: any tie order is valid there)."""
+    return torch.sort(composite_key(*cols), stable=True).indices
+
+
+def lexargunique(*cols):
+    """Index of the first occurrence of each distinct row, rows in
+    lexicographic order (cpu_lex_op 'argunique', utils/multimodal.py:308-312)."""
+    key = composite_key(*cols)
+    if key.shape[0] == 0:
+        return key
+    order = torch.sort(key, stable=True).indices
+    ks = key[order]
+    first = torch.ones_like(ks, dtype=torch.bool)
+    first[1:] = ks[1:] != ks[:-1]
+    return order[first]
+
+
+def lexunique(col):
+    return torch.unique(col, sorted=True)
+
+
+class ImageMapping(CSRData):
+
+    @staticmethod
+    def from_dense(point_ids, image_ids, pixels, features, num_points=None):
+        """Build the nested CSR from one row per (point, image, pixel)
+        (core/multimodal/image.py:1738-1805).  Pixels of one (point, image)
+        group come out in (x, y) order."""
+        assert point_ids.ndim == 1, 'point_ids and image_ids must be 1D tensors'
+        assert point_ids.shape == image_ids.shape, \
+            'point_ids and image_ids must have the same shape'
+        assert point_ids.shape[0] == pixels.shape[0], \
+            'pixels and indices must have the same shape'
+        assert features is None or point_ids.shape[0] == features.shape[0], \
+            'point_ids and features must have the same shape'
+        in_device = point_ids.device
+        if not in_device.type == 'cuda':
+            from . import _lib as L
+            dev = L.require_device()
+            point_ids, image_ids, pixels = point_ids.to(dev), image_ids.to(dev), pixels.to(dev)
+            features = features.to(dev) if features is not None else None
+
+        order = lexargsort(point_ids, image_ids, pixels[:, 0], pixels[:, 1])
+        point_ids, image_ids, pixels = point_ids[order], image_ids[order], pixels[order]
+        if features is not None:
+            features = features[order]
+
+        view_ids = composite_key(point_ids, image_ids)
+        image_pixel_mappings = CSRData(view_ids, pixels, dense=True)
+        last = image_pixel_mappings.pointers[1:] - 1
+        image_ids = image_ids[last]
+        point_ids = point_ids[last]
+        if features is not None:
+            features = _pooling.segment_csr(
+                features.float(), image_pixel_mappings.pointers, reduce='mean')
+            mapping = ImageMapping(
+                point_ids, image_ids, image_pixel_mappings, features, dense=True,
+                is_index_value=[True, False, False])
+        else:
+            mapping = ImageMapping(
+                point_ids, image_ids, image_pixel_mappings, dense=True,
+                is_index_value=[True, False])
+
+        if num_points is None or num_points < point_ids.max() + 1:
+            num_points = int(point_ids.max()) + 1
+        point_ids = point_ids[mapping.pointers[1:] - 1]
+        mapping = mapping.insert_empty_groups(point_ids, num_groups=num_points)
+        return mapping.to(in_device)
+
+    @staticmethod
+    def from_csr_arrays(pointers, images, pixels, features, view_pointers=None):
+        """Wrap already-built CSR arrays (the fused MapImages path)."""
+        if view_pointers is None:
+            view_pointers = torch.arange(
+                images.shape[0] + 1, dtype=torch.int64, device=images.device)
+        nested = CSRData(view_pointers, pixels, dense=False)
+        if features is None:
+            return ImageMapping(pointers, images, nested, dense=False,
+                                is_index_value=[True, False])
+        return ImageMapping(pointers, images, nested, features, dense=False,
+                            is_index_value=[True, False, False])
+
+    def debug(self):
+        super(ImageMapping, self).debug()
+        assert len(self.values) == 2 or self.has_features
+        assert isinstance(self.values[1], CSRData)
+        assert len(self.values[1].values) == 1
+
+    @property
+    def points(self):
+        return torch.arange(self.num_groups, device=self.device)
+
+    @property
+    def images(self):
+        return self.values[0]
+
+    @images.setter
+    def images(self, images):
+        self.values[0] = images.to(self.device)
+
+    @property
+    def has_features(self):
+        return len(self.values) == 3
+
+    @property
+    def features(self):
+        return self.values[2] if self.has_features else None
+
+    @features.setter
+    def features(self, features):
+        if self.has_features:
+            if features is None:
+                self.values.pop(-1)
+            else:
+                self.values[2] = features.to(self.device)
+        elif features is not None:
+            self.values.append(features.to(self.device))
+
+    @property
+    def pixels(self):
+        return self.values[1].values[0]
+
+    @pixels.setter
+    def pixels(self, pixels):
+        self.values[1].values[0] = pixels.to(self.device)
+
+    @staticmethod
+    def get_batch_type():
+        return ImageMappingBatch
+
+    @property
+    def feature_map_indexing(self):
+        """Index tuple for ``X[idx]`` on ``X`` of shape [B, C, H, W]
+        (core/multimodal/image.py:1881-1895)."""
+        sizes = self.values[1].pointers[1:] - self.values[1].pointers[:-1]
+        idx_batch = self.images.repeat_interleave(sizes)
+        return (idx_batch.long(), ..., self.pixels[:, 1].long(), self.pixels[:, 0].long())
+
+    @property
+    def atomic_csr_indexing(self):
+        """Pointers for the pixel -> view pooling (:1897-1902)."""
+        return self.values[1].pointers
+
+    @property
+    def view_csr_indexing(self):
+        """Pointers for the view -> point pooling (:1904-1909)."""
+        return self.pointers
+
+
+class ImageMappingBatch(ImageMapping, CSRBatch):
+    """Batch of ImageMappings (core/multimodal/image.py:2355-2400)."""
+    __csr_type__ = ImageMapping

@@ -1,0 +1,323 @@
+"""``MapImages``: point -> image -> pixel mapping of one sample, with the
+interface of ``torch_points3d/core/data_transform/multimodal/image.py``
+(``ImageTransform`` :29-61, ``MapImages`` :162-428).
+
+Two execution plans, same results as the reference's CPU path:
+
+* fused (``SplattingVisibility`` with ``exact=True``, pinhole cameras, integer
+  ``proj_upscale`` / ``downscale``, distinct mapping ids -- the shipped
+  KITTI-360 / WildScenes configuration): every view of the sample goes through
+  one launch set of ``mvf_map_images_exact`` which also assembles the nested
+  CSR on the device; nothing is sorted.
+* per view (anything else the HIP kernels support): the reference's own loop --
+  visibility model, pixel conversion, duplicate removal, ``from_dense`` -- with
+  each step on the device.
+
+Local point order.  The reference hands each view the points returned by an
+sklearn ``KDTree(leaf_size=50).query_radius`` (transforms.py:301-405), i.e. in
+the tree's traversal order; depth ties and shared centre pixels are resolved on
+that order.  ``point_order='kdtree'`` (default) rebuilds that order on the host
+for bit-identical results; ``point_order='index'`` uses the array order and
+needs no host work; a precomputed permutation may be supplied as
+``data.mvf_point_order``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import visibility as visibility_module
+from .images import ImageData, SameSettingImageData
+from .mapping import ImageMapping, lexargunique, lexunique
+
+MAPPING_KEY = 'mapping_index'
+ORDER_KEY = 'mvf_point_order'
+
+
+class ImageTransform:
+    """Transforms on ``Data`` and ``ImageData`` / ``SameSettingImageData``
+    (image.py:29-61)."""
+
+    _PROCESS_IMAGE_DATA = False
+
+    def _process(self, data, images):
+        raise NotImplementedError
+
+    def __call__(self, data, images):
+        if isinstance(data, list):
+            assert isinstance(images, list) and len(data) == len(images), \
+                f"List(Data) items and List(SameSettingImageData) must " \
+                f"have the same lengths."
+            out = [self.__call__(da, im) for da, im in zip(data, images)]
+            data_out, images_out = [list(x) for x in zip(*out)]
+        elif isinstance(images, ImageData) and not self._PROCESS_IMAGE_DATA:
+            out = [self.__call__(data.clone(), im) for im in images]
+            images_out = ImageData([im for _, im in out])
+            data_out = out[0][0] if len(out) > 0 else data
+        else:
+            data_out, images_out = self._process(data, images)
+        return data_out, images_out
+
+    def __repr__(self):
+        attr_repr = ', '.join([f'{k}={v}' for k, v in self.__dict__.items()])
+        return f'{self.__class__.__name__}({attr_repr})'
+
+
+_NO_MAPPING_MSG = (
+    "No mappings were found between the 3D points and any "
+    "of the provided images. This will cause errors in the "
+    "subsequent operations. Make sure your images are "
+    "located in the vicinity of your point cloud and that "
+    "the projection parameters allow for at least one "
+    "point-image-pixel mapping before re-running this "
+    "transformation.")
+
+
+def kdtree_order(pos, cylinder):
+    """Traversal order of the KD-tree the reference's radius samplers build
+    (transforms.py:326,380): ``query_radius`` returns the points of that order
+    that fall inside the radius."""
+    from sklearn.neighbors import KDTree
+    p = np.asarray(pos.detach().cpu())
+    tree = KDTree(p[:, :2] if cylinder else p, leaf_size=50)
+    return torch.from_numpy(np.asarray(tree.idx_array).astype(np.int64))
+
+
+def pack_views(images, camera):
+    """[V] mvf_view structs as a host uint8 tensor."""
+    V = images.num_views
+    arr = (L.MvfView * V)()
+    K = images.intrinsic_pinhole.float()
+    for v in range(V):
+        arr[v] = visibility_module.make_view(
+            images.pos[v].float(), K[v], images.extrinsic[v].float(), camera,
+            centre=images.pos[v].double(), crop_offsets=images.crop_offsets[v].tolist())
+    buf = np.frombuffer(arr, dtype=np.uint8).copy()
+    return torch.from_numpy(buf)
+
+
+class _CentreWorkspace:
+    """Persistent per-device uint64 map shared by successive fused calls: it is
+    zeroed once, every call tags its entries with a fresh epoch."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, device, n_elems):
+        key = (device.index, )
+        ws = cls._cache.get(key)
+        if ws is None or ws[0].numel() < n_elems or ws[1] >= 2 ** 32 - 2:
+            ws = [torch.zeros(n_elems, dtype=torch.int64, device=device), 0]
+            cls._cache[key] = ws
+        ws[1] += 1
+        return ws[0], ws[1]
+
+
+class MapImages(ImageTransform):
+    """Computes the mappings between individual 3D points and image pixels
+    (image.py:162-428).  Returns the input data and the images augmented with
+    the point-image-pixel ``ImageMapping``; views without any mapping are
+    dropped."""
+
+    def __init__(
+            self, method='SplattingVisibility', proj_upscale=None,
+            ref_size=None, use_cuda=False, verbose=False, cylinder=False,
+            **kwargs):
+        self.key = MAPPING_KEY
+        self.verbose = verbose
+        self.cylinder = cylinder
+        self.ref_size = ref_size
+        self.proj_upscale = proj_upscale
+        self.method = method
+        # computation always runs on the HIP device; kept for signature parity
+        self.use_cuda = use_cuda
+        self.point_order = kwargs.pop('point_order', 'kdtree')
+        assert self.point_order in ('kdtree', 'index')
+        self.kwargs = kwargs
+        self._pair_cap = None
+        self._out_cap = None
+        self.timings = {}
+
+    # ------------------------------------------------------------------ #
+    def _order(self, data):
+        order = getattr(data, ORDER_KEY, None)
+        if order is not None:
+            return order
+        if self.point_order == 'index':
+            return None
+        return kdtree_order(data.pos, self.cylinder)
+
+    def _fusable(self, images, visi_model):
+        ints = all(float(s).is_integer() and s >= 1
+                   for s in (images.proj_upscale, images.downscale))
+        return (self.method == 'SplattingVisibility' and bool(visi_model.exact)
+                and visi_model.camera in ('kitti360_perspective', 'scannet')
+                and ints and images.pixel_dtype == torch.int16
+                and images.is_pinhole and images.has_extrinsic)
+
+    def _process(self, data, images):
+        assert hasattr(data, self.key)
+        assert images.num_views >= 1, "At least one image must be provided."
+        in_device = images.device
+        device = L.require_device(data.pos)
+
+        if self.ref_size is not None:
+            images.ref_size = self.ref_size
+        if self.proj_upscale is not None:
+            images.proj_upscale = self.proj_upscale
+        if images.mask is not None:
+            assert tuple(images.mask.shape) == tuple(images.proj_size)
+
+        visi_cls = getattr(visibility_module, self.method)
+        visi_model = visi_cls(img_size=images.proj_size, **self.kwargs)
+
+        mappings = seen = None
+        if self._fusable(images, visi_model):
+            res = self._process_fused(data, images, visi_model, device)
+            if res is not None:
+                mappings, seen = res
+        if mappings is None:
+            mappings, seen = self._process_per_view(data, images, visi_model, device)
+
+        if seen.shape[0] != images.num_views:
+            images = images[seen.to(in_device)]
+        images.mappings = mappings.to(in_device)
+        images.visibility = visi_model
+        return data, images
+
+    # ------------------------------------------------------------------ #
+    def _process_fused(self, data, images, visi_model, device):
+        lib = L.load()
+        N = data.pos.shape[0]
+        V = images.num_views
+        order = self._order(data)
+        ids = getattr(data, self.key).to(device=device, dtype=torch.int64)
+        pos = data.pos.to(device=device, dtype=torch.float32)
+        attrs = [getattr(data, k, None) for k in ('linearity', 'planarity', 'scattering', 'norm')]
+        attrs = [a.to(device=device, dtype=torch.float32) if a is not None else None for a in attrs]
+        if order is not None:
+            order = order.to(device)
+            pos, ids = pos[order], ids[order]
+            attrs = [a[order] if a is not None else None for a in attrs]
+        pos = pos.contiguous()
+        attrs = [a.contiguous() if a is not None else None for a in attrs]
+        num_points = int(ids.max().item()) + 1
+        inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
+        inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
+        if int((inv >= 0).sum().item()) != N or int(ids.min().item()) < 0:
+            return None      # repeated mapping ids: several pixels per (point, view)
+
+        params = visibility_module.make_params(**visi_model.__dict__)
+        W, H = params.W, params.H
+        Hc = H - params.crop_top - params.crop_bottom
+        views = pack_views(images, visi_model.camera).to(device)
+        mask = images.mask.to(device=device, dtype=torch.uint8).contiguous() \
+            if images.mask is not None else None
+        F = 2 + sum(a is not None for a in attrs)
+        centre_ws, epoch = _CentreWorkspace.get(device, V * W * Hc)
+        counters = torch.zeros(4, dtype=torch.int64, device=device)
+        pointers = torch.empty(num_points + 1, dtype=torch.int64, device=device)
+        view_seen = torch.empty(V, dtype=torch.int32, device=device)
+        pair_cap = self._pair_cap or (N * V // 4 + 4096)
+        out_cap = self._out_cap or (N * V // 4 + 4096)
+        for _ in range(3):
+            img_ids = torch.empty(out_cap, dtype=torch.int64, device=device)
+            pixels = torch.empty((out_cap, 2), dtype=torch.int16, device=device)
+            feats = torch.empty((out_cap, F), dtype=torch.float32, device=device)
+            ws = L.workspace(lib.mvf_map_images_workspace_bytes(
+                N, V, W, H, num_points, pair_cap), device)
+            with torch.cuda.device(device):
+                L.check(lib.mvf_map_images_exact(
+                    L.ptr(pos), L.ptr(ids), L.ptr(inv), N, num_points, L.ptr(views), V,
+                    C.byref(params), int(bool(self.cylinder)), L.ptr(mask),
+                    *[L.ptr(a) for a in attrs], int(images.proj_upscale),
+                    int(images.downscale), int(images.crop_size[0]), int(images.crop_size[1]),
+                    L.ptr(centre_ws), epoch, pair_cap, L.ptr(pointers), L.ptr(img_ids),
+                    L.ptr(pixels), L.ptr(feats), out_cap, L.ptr(view_seen), L.ptr(counters),
+                    L.ptr(ws), ws.numel(), L.stream_ptr(device)))
+            n_map, pairs, overflow, n_seen = counters.tolist()
+            if not overflow:
+                break
+            pair_cap = max(pair_cap, int(pairs * 1.1) + 4096)
+            out_cap = max(out_cap, int(n_map * 1.1) + 4096)
+            centre_ws, epoch = _CentreWorkspace.get(device, V * W * Hc)
+        else:
+            raise L.MvfError("MapImages: buffers still too small after retries")
+        self._pair_cap = max(pair_cap, int(pairs * 1.1) + 4096)
+        self._out_cap = max(out_cap, int(n_map * 1.1) + 4096)
+        if n_map == 0:
+            raise ValueError(_NO_MAPPING_MSG)
+        mappings = ImageMapping.from_csr_arrays(
+            pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map])
+        seen = torch.where(view_seen > 0)[0]
+        return mappings, seen
+
+    # ------------------------------------------------------------------ #
+    def _process_per_view(self, data, images, visi_model, device):
+        N = data.pos.shape[0]
+        order = self._order(data)
+        order = torch.arange(N, device=device) if order is None else order.to(device)
+        pos = data.pos.to(device)
+        pos64 = pos.double()[order]
+        pos32 = pos.float()
+        ids = getattr(data, self.key).to(device=device, dtype=torch.int64)
+        attrs = {k: getattr(data, a, None) for k, a in (
+            ('linearity', 'linearity'), ('planarity', 'planarity'),
+            ('scattering', 'scattering'), ('normals', 'norm'))}
+        attrs = {k: (a.to(device).float() if a is not None else None) for k, a in attrs.items()}
+        K = images.intrinsic_pinhole.float() if images.is_pinhole else None
+        r = float(visi_model.r_max)
+
+        image_ids, point_ids, features, pixels = [], [], [], []
+        for v in range(images.num_views):
+            c = images.pos[v].double().to(device)
+            d2 = (pos64[:, 0] - c[0]) ** 2 + (pos64[:, 1] - c[1]) ** 2
+            if not self.cylinder:
+                d2 = d2 + (pos64[:, 2] - c[2]) ** 2
+            local = order[d2 <= r * r]
+            extra = {}
+            if getattr(images, 'depth_maps', None) is not None:
+                extra['depth_map'] = images.depth_maps[v]
+            out_vm = visi_model(
+                pos32[local], images.pos[v].float(),
+                img_intrinsic_pinhole=K[v] if K is not None else None,
+                img_extrinsic=images.extrinsic[v].float() if images.has_extrinsic else None,
+                img_mask=images.mask if images.mask is not None else None,
+                **{k: (a[local] if a is not None else None) for k, a in attrs.items()},
+                **extra)
+            if out_vm['idx'].shape[0] == 0:
+                continue
+            point_ids_ = ids[local][out_vm['idx']]
+            pix_x_ = out_vm['x'].long()
+            pix_y_ = out_vm['y'].long()
+            features_ = out_vm['features'].float()
+            pix_x_ = pix_x_ // images.proj_upscale
+            pix_y_ = pix_y_ // images.proj_upscale
+            pix_x_ = pix_x_ - images.crop_offsets[v][0].item()
+            pix_y_ = pix_y_ - images.crop_offsets[v][1].item()
+            in_crop = torch.where(
+                (pix_x_ >= 0) & (pix_y_ >= 0) & (pix_x_ < images.crop_size[0])
+                & (pix_y_ < images.crop_size[1]))
+            pix_x_, pix_y_ = pix_x_[in_crop], pix_y_[in_crop]
+            point_ids_, features_ = point_ids_[in_crop], features_[in_crop]
+            pix_x_ = (pix_x_ // images.downscale).long()
+            pix_y_ = (pix_y_ // images.downscale).long()
+            unique_idx = lexargunique(point_ids_, pix_x_, pix_y_)
+            pixels_ = torch.stack((pix_x_[unique_idx], pix_y_[unique_idx]), dim=1).type(
+                images.pixel_dtype)
+            image_ids.append(v)
+            point_ids.append(point_ids_[unique_idx])
+            features.append(features_[unique_idx])
+            pixels.append(pixels_)
+
+        image_ids = torch.tensor(image_ids, dtype=torch.int64)
+        if image_ids.shape[0] == 0:
+            raise ValueError(_NO_MAPPING_MSG)
+        seen = lexunique(image_ids)
+        ranks = torch.bucketize(image_ids, seen)
+        dense_img = ranks.repeat_interleave(
+            torch.tensor([x.shape[0] for x in point_ids])).to(device)
+        mappings = ImageMapping.from_dense(
+            torch.cat(point_ids), dense_img, torch.cat(pixels), torch.cat(features),
+            num_points=int(ids.max().item()) + 1)
+        return mappings, seen
