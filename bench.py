@@ -1,0 +1,263 @@
+"""Benchmark of the multi-view image->point fusion hot path on MI355X.
+
+One "step" = one pass of the hot path over one sample resident in HBM:
+fused MapImages (projection + splat z-buffer visibility + CSR assembly for all
+views) followed by the atomic (pixel->view, max) and view (view->point, max and
+mean) CSR pools.  Metric: points x views mapped+fused per second (whole job, all
+ranks).  With N > 1 ranks every rank maps and pools its own sample (weak
+scaling) and the pooled features + labels are gathered once over RCCL at the
+end of the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-fusion_amd"))
+
+from mvfusion import _lib as L                      # noqa: E402
+from mvfusion import synthetic as S                 # noqa: E402
+from mvfusion.images import SameSettingImageData    # noqa: E402
+from mvfusion.pooling import segment_csr            # noqa: E402
+from mvfusion.transforms import MapImages, kdtree_order  # noqa: E402
+from mvfusion import visibility as visibility_module     # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec peak
+VIS = dict(voxel=0.05, r_max=20, r_min=0, k_swell=1.5, d_swell=1e6, exact=True,
+           camera="kitti360_perspective")
+WORKLOADS = {
+    "c1": dict(channels=64, label="KITTI-360-shaped cylinder, 100k pts x 8 views 1408x376"),
+    "c2": dict(channels=13, label="WildScenes-shaped scan, 300k pts x 16 views 2016x1512"),
+}
+
+
+class Data:
+    pass
+
+
+def stage_sample(cfg, seed, device):
+    """Build one synthetic sample on the host and stage it in HBM."""
+    sc = S.make_scene(cfg, seed=seed)
+    N = sc["xyz"].shape[0]
+    T = torch.from_numpy
+    data = Data()
+    data.pos = T(sc["xyz"])
+    data.mapping_index = torch.arange(N)
+    data.mvf_point_order = kdtree_order(data.pos, True)
+    images = SameSettingImageData(
+        pos=T(sc["pos"]), extrinsic=T(sc["extrinsic"]), fx=T(sc["fx"]), fy=T(sc["fy"]),
+        mx=T(sc["mx"]), my=T(sc["my"]), ref_size=sc["img_size"], proj_upscale=1)
+    t = MapImages(method="SplattingVisibility", cylinder=True, **VIS)
+    model = visibility_module.SplattingVisibility(img_size=images.proj_size, **VIS)
+    plan = t.prepare_fused(data, images, model, device)
+    return sc, plan
+
+
+def algorithmic_bytes(N, V, W, Hc, M, F, C):
+    """Closed-form byte model: xyz read once per view, one write + one read of
+    an 8-byte z-buffer cell per pixel, the emitted mappings, the output CSR,
+    and each pool reading its input once and writing its output once."""
+    Vw = P = M
+    b = {}
+    b["projection"] = V * 12 * N
+    b["zbuffer"] = V * 16 * W * Hc
+    b["emit"] = M * (8 + 4 + 4 + 4 * F)
+    b["csr"] = 8 * (N + 1) + 8 * Vw + 8 * (Vw + 1) + 4 * P + 4 * F * Vw
+    b["atomic_pool"] = 4 * C * P + 4 * C * Vw + 8 * (Vw + 1)
+    b["view_pool"] = 2 * (4 * C * Vw + 4 * C * N + 8 * (N + 1))     # max and mean
+    b["map"] = b["projection"] + b["zbuffer"] + b["emit"] + b["csr"]
+    b["total"] = b["map"] + b["atomic_pool"] + b["view_pool"]
+    return b
+
+
+# stage of mvf_map_images_exact -> share of the byte model it is charged with
+STAGE_BYTES = {
+    "bin_count": "projection", "tile_zbuffer": "zbuffer", "csr_fill": "emit+csr",
+}
+
+
+def cpu_baseline(cfg, C_feat, target_s=12.0):
+    """The CPU oracle (single-threaded C + numpy port of the reference's CPU
+    algorithm) on the same workload, timed on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvf_oracle as orc
+    sc = S.make_scene(cfg, seed=2)
+    N, V = sc["xyz"].shape[0], sc["pos"].shape[0]
+    order = kdtree_order(torch.from_numpy(sc["xyz"]), True).numpy()
+    rng = np.random.default_rng(0)
+    times = []
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        m = orc.map_images(sc["xyz"], np.arange(N), sc, order=order, ref_size=sc["img_size"],
+                           cylinder=True, **VIS)
+        t_map = time.perf_counter() - t0
+        Pn = m["pixels"].shape[0]
+        x_pix = rng.random((Pn, C_feat), dtype=np.float32)      # input staging, not timed
+        t2 = time.perf_counter()
+        xv = orc.segment_csr(x_pix, m["view_pointers"], "max")
+        orc.segment_csr(xv, m["pointers"], "max")
+        orc.segment_csr(xv, m["pointers"], "mean")
+        times.append(t_map + time.perf_counter() - t2)
+        if time.perf_counter() - t_all > target_s or len(times) >= 5:
+            break
+    med = float(np.median(times))
+    return dict(value=N * V / med, unit="points*views/s", cores=1, kind="port",
+                sample=f"{len(times)} full passes of the same workload "
+                       f"({N} pts x {V} views, map + pools), median {med:.3f} s/pass")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = args.config
+    C_feat = WORKLOADS[cfg]["channels"]
+    sc, plan = stage_sample(cfg, seed=2 + rank, device=device)
+    N, V = plan.N, plan.V
+    W, H = sc["img_size"]
+    gen = torch.Generator(device=device).manual_seed(rank)
+    labels = torch.randint(0, 19, (N,), device=device, generator=gen)
+    # pixel features for every possible mapping row, resident in HBM
+    plan.run()
+    cap = plan.out_cap
+    x_pix = torch.rand((cap, C_feat), device=device, generator=gen)
+    atomic_ptr = torch.arange(cap + 1, dtype=torch.int64, device=device)
+    lib = L.load()
+
+    def step():
+        pointers, img_ids, pixels, feats, view_seen = plan.run()
+        P = img_ids.shape[0]
+        x_view = segment_csr(x_pix[:P], atomic_ptr[:P + 1], reduce="max")
+        x_max = segment_csr(x_view, pointers, reduce="max")
+        x_mean = segment_csr(x_view, pointers, reduce="mean")
+        return x_max, x_mean, P
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if dist is not None:
+        # the path's only exchange: final gather of pooled features and labels
+        feats_all = torch.empty((world * N, 2 * C_feat), device=device)
+        labels_all = torch.empty(world * N, dtype=labels.dtype, device=device)
+        dist.all_gather_into_tensor(feats_all, torch.cat(out[:2], dim=1))
+        dist.all_gather_into_tensor(labels_all, labels)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel timing with HIP events on the launch stream (rank 0) ----
+    roofline = None
+    stages = {}
+    if rank == 0:
+        lib.mvf_profile_enable(1)
+        ms = (C.c_float * 16)()
+        names = (C.c_char_p * 16)()
+        pool_ms = {"atomic_pool": 0.0, "view_pool": 0.0}
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for _ in range(args.steps):
+            pointers, img_ids, pixels, feats, view_seen = plan.run()
+            n = lib.mvf_profile_read(ms, names, 16)
+            for i in range(n):
+                k = names[i].decode()
+                stages[k] = stages.get(k, 0.0) + ms[i]
+            P = img_ids.shape[0]
+            ev[0].record()
+            x_view = segment_csr(x_pix[:P], atomic_ptr[:P + 1], reduce="max")
+            ev[1].record()
+            segment_csr(x_view, pointers, reduce="max")
+            segment_csr(x_view, pointers, reduce="mean")
+            ev[2].record()
+            torch.cuda.synchronize()
+            pool_ms["atomic_pool"] += ev[0].elapsed_time(ev[1])
+            pool_ms["view_pool"] += ev[1].elapsed_time(ev[2])
+        lib.mvf_profile_enable(0)
+        stages.update(pool_ms)
+        stages = {k: v / args.steps for k, v in stages.items()}          # ms per step
+        M = plan.last_counts["mappings"]
+        F = plan.F
+        Hc = H
+        B = algorithmic_bytes(N, V, W, Hc, M, F, C_feat)
+        charged = {"bin_count": B["projection"], "tile_zbuffer": B["zbuffer"],
+                   "csr_fill": B["emit"] + B["csr"], "atomic_pool": B["atomic_pool"],
+                   "view_pool": B["view_pool"]}
+        dom = max(charged, key=lambda k: stages.get(k, 0.0))
+        ach = charged[dom] / (stages[dom] * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(cfg, {}).get(dom)
+        roofline = dict(
+            bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+            frac=ach / HBM_PEAK, traffic=traffic,
+            algorithmic_bytes_per_launch=charged[dom], kernel_ms=stages[dom],
+            pipeline=dict(
+                algorithmic_bytes_per_step=B["total"],
+                ms_per_step=elapsed / args.steps * 1e3,
+                achieved=B["total"] / (elapsed / args.steps) / 1e9,
+                frac=B["total"] / (elapsed / args.steps) / HBM_PEAK),
+            stage_ms={k: round(v, 4) for k, v in stages.items()})
+
+    if rank == 0:
+        line = {
+            "metric": "points*views mapped+fused/sec",
+            "value": world * N * V * args.steps / elapsed,
+            "unit": "points*views/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOADS[cfg]["label"]
+                       + f", exact splat visibility + max atomic pool + max/mean view pools (C={C_feat})",
+                       "name": cfg, "points_per_gpu": N, "views": V, "image": [W, H],
+                       "mappings_per_sample": plan.last_counts["mappings"],
+                       "splat_tile_pairs": plan.last_counts["pairs"],
+                       "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, C_feat)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

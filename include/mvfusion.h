@@ -70,6 +70,17 @@ typedef struct {
 int mvf_version(void);
 const char *mvf_last_error(void);
 
+/* Per-stage timing of the multi-kernel entry points with HIP events recorded on
+ * the call's own stream (no counterpart in the reference; it exists for
+ * bench.py's roofline figures).  State is per host thread.  After enabling,
+ * each profiled call (mvf_map_images_exact) records one event per stage; once
+ * the stream is synchronised mvf_profile_read fills h_ms[i] with the elapsed
+ * milliseconds of stage i and h_names[i] (may be NULL) with its name, and
+ * returns the number of stages (0 if nothing was recorded). */
+#define MVF_PROFILE_MAX_STAGES 16
+int mvf_profile_enable(int enable);
+int mvf_profile_read(float *h_ms, const char **h_names, int capacity);
+
 /* ---------------------------------------------------------------------- *
  * camera_projection  (visibility.py:478-538,592-623; pinhole cameras)
  * Keeps points with r_min < dist < r_max that project inside the (cropped)

@@ -46,6 +46,10 @@ void set_error(const char *fmt, ...);
         }                                                                    \
     } while (0)
 
+// Stage timing hooks (no-ops unless mvf_profile_enable(1) was called on this thread).
+void prof_begin(hipStream_t st);
+void prof_mark(const char *name, hipStream_t st);
+
 static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace.

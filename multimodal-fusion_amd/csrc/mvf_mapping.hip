@@ -636,35 +636,45 @@ extern "C" int mvf_map_images_exact(
     int *view_rank = ar.take<int>(V);
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
+    prof_begin(st);
     MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
     MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
     MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int), st));
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
+    prof_mark("memset", st);
     hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true>), grid_nv, block, 0, st, src, P, tiles_y,
                        tiles_per_view, tile_count, seen, (i64)n);
+    prof_mark("bin_count", st);
     exclusive_scan<unsigned, unsigned, i64>(tile_count, tiles, tile_off, scan_ws, (i64 *)counters + 1, st);
+    prof_mark("tile_scan", st);
     hipLaunchKernelGGL((bin_fill_kernel<CloudSrc>), grid_nv, block, 0, st, src, P, tiles_y,
                        tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
                        (i64 *)counters + 2);
+    prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
                        tile_off, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc, seen, (i64)n,
                        (unsigned *)nullptr);
+    prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL(mi_centre_kernel, grid_nv, block, 0, st, src, P, seen, Hc, (u64 *)centre_ws, epoch);
+    prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q(cdiv(num_points, 256));
     hipLaunchKernelGGL(mi_point_count_kernel, grid_q, block, 0, st, src, P, seen, Hc,
                        (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points, cnt,
                        view_seen);
+    prof_mark("point_count", st);
     exclusive_scan<unsigned, i64, i64>(cnt, num_points, (i64 *)pointers, scan_ws64, (i64 *)counters, st);
+    prof_mark("point_scan", st);
     hipLaunchKernelGGL(mi_view_rank_kernel, dim3(1), dim3(64), 0, st, view_seen, V, view_rank,
                        (i64 *)counters + 3);
     hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, 0, st, src, P, seen, Hc, (const u64 *)centre_ws,
                        epoch, X, V, (const i64 *)inv_ids, (i64)num_points, (const i64 *)pointers,
                        view_rank, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)images, pixels, features, (i64 *)counters + 2);
+    prof_mark("csr_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

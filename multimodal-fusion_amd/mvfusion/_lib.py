@@ -49,6 +49,8 @@ _SZ = C.c_size_t
 _SIGNATURES = {
     "mvf_version": (C.c_int, []),
     "mvf_last_error": (C.c_char_p, []),
+    "mvf_profile_enable": (C.c_int, [C.c_int]),
+    "mvf_profile_read": (C.c_int, [_P, _P, C.c_int]),
     "mvf_camera_projection_workspace_bytes": (_SZ, [_I64]),
     "mvf_camera_projection": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "mvf_splat_visibility_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I64]),

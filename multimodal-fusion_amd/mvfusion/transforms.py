@@ -113,6 +113,74 @@ class _CentreWorkspace:
         return ws[0], ws[1]
 
 
+class FusedMapPlan:
+    """One sample staged on the device for ``mvf_map_images_exact`` plus the
+    output / workspace buffers, which are reused from run to run and grown when
+    the library reports an overflow."""
+
+    def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
+                 downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None):
+        self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
+        self.views, self.mask, self.params = views, mask, params
+        self.cylinder, self.upscale, self.downscale, self.crop_size = \
+            cylinder, upscale, downscale, crop_size
+        self.N, self.V, self.num_points, self.device = pos.shape[0], V, num_points, device
+        self.F = 2 + sum(a is not None for a in attrs)
+        self.pair_cap = pair_cap or (self.N * V // 4 + 4096)
+        self.out_cap = out_cap or (self.N * V // 4 + 4096)
+        self.counters = torch.zeros(4, dtype=torch.int64, device=device)
+        self.pointers = torch.empty(num_points + 1, dtype=torch.int64, device=device)
+        self.view_seen = torch.empty(V, dtype=torch.int32, device=device)
+        self._bufs = None
+        self.last_counts = None
+
+    def _buffers(self):
+        lib = L.load()
+        if self._bufs is None or self._bufs[0] != (self.pair_cap, self.out_cap):
+            d = self.device
+            ws_bytes = lib.mvf_map_images_workspace_bytes(
+                self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
+            self._bufs = ((self.pair_cap, self.out_cap),
+                          torch.empty(self.out_cap, dtype=torch.int64, device=d),
+                          torch.empty((self.out_cap, 2), dtype=torch.int16, device=d),
+                          torch.empty((self.out_cap, self.F), dtype=torch.float32, device=d),
+                          L.workspace(ws_bytes, d))
+        return self._bufs[1:]
+
+    def launch(self):
+        """Enqueue one fused mapping pass (no synchronisation)."""
+        lib = L.load()
+        P = self.params
+        Hc = P.H - P.crop_top - P.crop_bottom
+        centre_ws, epoch = _CentreWorkspace.get(self.device, self.V * P.W * Hc)
+        img_ids, pixels, feats, ws = self._buffers()
+        with torch.cuda.device(self.device):
+            L.check(lib.mvf_map_images_exact(
+                L.ptr(self.pos), L.ptr(self.ids), L.ptr(self.inv), self.N, self.num_points,
+                L.ptr(self.views), self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
+                *[L.ptr(a) for a in self.attrs], self.upscale, self.downscale,
+                int(self.crop_size[0]), int(self.crop_size[1]), L.ptr(centre_ws), epoch,
+                self.pair_cap, L.ptr(self.pointers), L.ptr(img_ids), L.ptr(pixels),
+                L.ptr(feats), self.out_cap, L.ptr(self.view_seen), L.ptr(self.counters),
+                L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
+        return img_ids, pixels, feats
+
+    def run(self):
+        """Mapping pass + read-back of the data-dependent sizes (one
+        synchronisation); repeats with larger buffers after an overflow.
+        Returns pointers, images, pixels, features, view_seen."""
+        for _ in range(3):
+            img_ids, pixels, feats = self.launch()
+            n_map, pairs, overflow, n_seen = self.counters.tolist()
+            self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
+            if not overflow:
+                return self.pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], \
+                    self.view_seen
+            self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
+            self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
+        raise L.MvfError("MapImages: buffers still too small after retries")
+
+
 class MapImages(ImageTransform):
     """Computes the mappings between individual 3D points and image pixels
     (image.py:162-428).  Returns the input data and the images augmented with
@@ -186,10 +254,11 @@ class MapImages(ImageTransform):
         return data, images
 
     # ------------------------------------------------------------------ #
-    def _process_fused(self, data, images, visi_model, device):
-        lib = L.load()
+    def prepare_fused(self, data, images, visi_model, device):
+        """Stage one sample on the device for the fused path: points permuted
+        into the sampler's order, mapping ids and their inverse, packed views.
+        Returns a FusedMapPlan, or None when mapping ids repeat."""
         N = data.pos.shape[0]
-        V = images.num_views
         order = self._order(data)
         ids = getattr(data, self.key).to(device=device, dtype=torch.int64)
         pos = data.pos.to(device=device, dtype=torch.float32)
@@ -199,58 +268,31 @@ class MapImages(ImageTransform):
             order = order.to(device)
             pos, ids = pos[order], ids[order]
             attrs = [a[order] if a is not None else None for a in attrs]
-        pos = pos.contiguous()
-        attrs = [a.contiguous() if a is not None else None for a in attrs]
         num_points = int(ids.max().item()) + 1
         inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
         inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
         if int((inv >= 0).sum().item()) != N or int(ids.min().item()) < 0:
             return None      # repeated mapping ids: several pixels per (point, view)
+        return FusedMapPlan(
+            pos.contiguous(), ids.contiguous(), inv,
+            [a.contiguous() if a is not None else None for a in attrs],
+            pack_views(images, visi_model.camera).to(device),
+            images.mask.to(device=device, dtype=torch.uint8).contiguous()
+            if images.mask is not None else None,
+            visibility_module.make_params(**visi_model.__dict__), bool(self.cylinder),
+            int(images.proj_upscale), int(images.downscale), tuple(images.crop_size),
+            images.num_views, num_points, device, self._pair_cap, self._out_cap)
 
-        params = visibility_module.make_params(**visi_model.__dict__)
-        W, H = params.W, params.H
-        Hc = H - params.crop_top - params.crop_bottom
-        views = pack_views(images, visi_model.camera).to(device)
-        mask = images.mask.to(device=device, dtype=torch.uint8).contiguous() \
-            if images.mask is not None else None
-        F = 2 + sum(a is not None for a in attrs)
-        centre_ws, epoch = _CentreWorkspace.get(device, V * W * Hc)
-        counters = torch.zeros(4, dtype=torch.int64, device=device)
-        pointers = torch.empty(num_points + 1, dtype=torch.int64, device=device)
-        view_seen = torch.empty(V, dtype=torch.int32, device=device)
-        pair_cap = self._pair_cap or (N * V // 4 + 4096)
-        out_cap = self._out_cap or (N * V // 4 + 4096)
-        for _ in range(3):
-            img_ids = torch.empty(out_cap, dtype=torch.int64, device=device)
-            pixels = torch.empty((out_cap, 2), dtype=torch.int16, device=device)
-            feats = torch.empty((out_cap, F), dtype=torch.float32, device=device)
-            ws = L.workspace(lib.mvf_map_images_workspace_bytes(
-                N, V, W, H, num_points, pair_cap), device)
-            with torch.cuda.device(device):
-                L.check(lib.mvf_map_images_exact(
-                    L.ptr(pos), L.ptr(ids), L.ptr(inv), N, num_points, L.ptr(views), V,
-                    C.byref(params), int(bool(self.cylinder)), L.ptr(mask),
-                    *[L.ptr(a) for a in attrs], int(images.proj_upscale),
-                    int(images.downscale), int(images.crop_size[0]), int(images.crop_size[1]),
-                    L.ptr(centre_ws), epoch, pair_cap, L.ptr(pointers), L.ptr(img_ids),
-                    L.ptr(pixels), L.ptr(feats), out_cap, L.ptr(view_seen), L.ptr(counters),
-                    L.ptr(ws), ws.numel(), L.stream_ptr(device)))
-            n_map, pairs, overflow, n_seen = counters.tolist()
-            if not overflow:
-                break
-            pair_cap = max(pair_cap, int(pairs * 1.1) + 4096)
-            out_cap = max(out_cap, int(n_map * 1.1) + 4096)
-            centre_ws, epoch = _CentreWorkspace.get(device, V * W * Hc)
-        else:
-            raise L.MvfError("MapImages: buffers still too small after retries")
-        self._pair_cap = max(pair_cap, int(pairs * 1.1) + 4096)
-        self._out_cap = max(out_cap, int(n_map * 1.1) + 4096)
-        if n_map == 0:
+    def _process_fused(self, data, images, visi_model, device):
+        plan = self.prepare_fused(data, images, visi_model, device)
+        if plan is None:
+            return None
+        pointers, img_ids, pixels, feats, view_seen = plan.run()
+        self._pair_cap, self._out_cap = plan.pair_cap, plan.out_cap
+        if img_ids.shape[0] == 0:
             raise ValueError(_NO_MAPPING_MSG)
-        mappings = ImageMapping.from_csr_arrays(
-            pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map])
-        seen = torch.where(view_seen > 0)[0]
-        return mappings, seen
+        mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)
+        return mappings, torch.where(view_seen > 0)[0]
 
     # ------------------------------------------------------------------ #
     def _process_per_view(self, data, images, visi_model, device):
