@@ -217,6 +217,7 @@ def main():
         charged = {"bin_count": B["projection"], "tile_zbuffer": B["zbuffer"],
                    "csr_fill": B["emit"] + B["csr"], "atomic_pool": B["atomic_pool"],
                    "view_pool": B["view_pool"]}
+        charged = {k: v for k, v in charged.items() if k in stages}
         dom = max(charged, key=lambda k: stages.get(k, 0.0))
         ach = charged[dom] / (stages[dom] * 1e-3)
         traffic = None

@@ -73,55 +73,126 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
 // ------------------------------------------------------------------------- //
 // binning: count, fill                                                        //
 // ------------------------------------------------------------------------- //
-template <class Src, bool ZERO_SEEN>
+// Consecutive points are close in space (the sampler's order), so the 256
+// points of a block touch few tiles.  Tile counters are therefore first
+// accumulated in an LDS histogram of the view's tiles and flushed with one
+// global atomic per touched tile: global atomics on the hot tile counters
+// otherwise serialise at the memory side.  Views with more than BIN_MAX_TILES
+// tiles use global atomics directly (USE_LDS = false).
+constexpr int BIN_MAX_TILES = 4096;
+
+template <class Src, bool ZERO_SEEN, bool USE_LDS>
 __global__ __launch_bounds__(256) void bin_count_kernel(
     Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
-    unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride)
+    unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride,
+    i64 *__restrict__ zero_counters, int *__restrict__ zero_view_seen, int V)
 {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ unsigned hist[];
+    const int tid = threadIdx.x;
+    const i64 i = (i64)blockIdx.x * 256 + tid;
     const int v = blockIdx.y;
-    if (i >= src.count()) return;
-    if (ZERO_SEEN) seen[(size_t)v * seen_stride + i] = 0;
+    // the first block also clears the caller's small output arrays
+    if (blockIdx.x == 0 && v == 0) {
+        if (zero_counters && tid < 4) zero_counters[tid] = 0;
+        if (zero_view_seen) for (int k = tid; k < V; k += 256) zero_view_seen[k] = 0;
+    }
+    const bool live = i < src.count();
+    if (ZERO_SEEN && live) seen[(size_t)v * seen_stride + i] = 0;
     double x, y; float d, fx, fy;
-    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
-    const BBox b = splat_bbox(x, y, d, fx, fy, P);
+    const bool have = live && src.get(i, v, P, x, y, d, fx, fy);
+    BBox b{0, 0, 0, 0};
+    if (have) b = splat_bbox(x, y, d, fx, fy, P);
     const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     unsigned *tc = tile_count + (size_t)v * tiles_per_view;
-    for (int tx = tx0; tx <= tx1; ++tx)
-        for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&tc[tx * tiles_y + ty], 1u);
+    if (USE_LDS) {
+        if (!__syncthreads_or(have)) return;
+        for (int t = tid; t < tiles_per_view; t += 256) hist[t] = 0;
+        __syncthreads();
+        if (have)
+            for (int tx = tx0; tx <= tx1; ++tx)
+                for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&hist[tx * tiles_y + ty], 1u);
+        __syncthreads();
+        for (int t = tid; t < tiles_per_view; t += 256) {
+            const unsigned c = hist[t];
+            if (c) atomicAdd(&tc[t], c);
+        }
+    } else if (have) {
+        for (int tx = tx0; tx <= tx1; ++tx)
+            for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&tc[tx * tiles_y + ty], 1u);
+    }
 }
 
-template <class Src>
+template <class Src, bool USE_LDS>
 __global__ __launch_bounds__(256) void bin_fill_kernel(
     Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
     const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
     TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
 {
-    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ unsigned hist[];          // [tiles_per_view] counts, then [tiles_per_view] bases
+    const int tid = threadIdx.x;
+    const i64 i = (i64)blockIdx.x * 256 + tid;
     const int v = blockIdx.y;
-    if (i >= src.count()) return;
-    double x, y; float d, fx, fy;
-    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
-    const BBox b = splat_bbox(x, y, d, fx, fy, P);
+    double x, y; float d = 0.f, fx, fy;
+    const bool have = i < src.count() && src.get(i, v, P, x, y, d, fx, fy);
+    BBox b{0, 0, 0, 0};
+    if (have) b = splat_bbox(x, y, d, fx, fy, P);
     const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     TileEntry e;
     e.key = depth_key(d, (unsigned)i);
     e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
     const size_t tbase = (size_t)v * tiles_per_view;
-    for (int tx = tx0; tx <= tx1; ++tx)
-        for (int ty = ty0; ty <= ty1; ++ty) {
-            const size_t t = tbase + tx * tiles_y + ty;
-            const i64 pos = (i64)tile_off[t] + atomicAdd(&tile_cur[t], 1u);
-            if (pos < pair_capacity) entries[pos] = e;
-            else *overflow = 1;
+    if (USE_LDS) {
+        if (!__syncthreads_or(have)) return;
+        unsigned *base = hist + tiles_per_view;
+        for (int t = tid; t < tiles_per_view; t += 256) hist[t] = 0;
+        __syncthreads();
+        if (have)
+            for (int tx = tx0; tx <= tx1; ++tx)
+                for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&hist[tx * tiles_y + ty], 1u);
+        __syncthreads();
+        // one global reservation per touched tile; hist becomes the local cursor
+        for (int t = tid; t < tiles_per_view; t += 256) {
+            const unsigned c = hist[t];
+            if (c) base[t] = atomicAdd(&tile_cur[tbase + t], c);
+            hist[t] = 0;
         }
+        __syncthreads();
+        if (have)
+            for (int tx = tx0; tx <= tx1; ++tx)
+                for (int ty = ty0; ty <= ty1; ++ty) {
+                    const int t = tx * tiles_y + ty;
+                    const i64 pos = (i64)tile_off[tbase + t] + base[t] + atomicAdd(&hist[t], 1u);
+                    if (pos < pair_capacity) entries[pos] = e;
+                    else *overflow = 1;
+                }
+    } else if (have) {
+        for (int tx = tx0; tx <= tx1; ++tx)
+            for (int ty = ty0; ty <= ty1; ++ty) {
+                const size_t t = tbase + tx * tiles_y + ty;
+                const i64 pos = (i64)tile_off[t] + atomicAdd(&tile_cur[t], 1u);
+                if (pos < pair_capacity) entries[pos] = e;
+                else *overflow = 1;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------- //
 // z-buffer of one tile in LDS                                                 //
 // ------------------------------------------------------------------------- //
+// LDS image: zb[x][y ^ bitrev5(x)], 8-byte keys.  The XOR spreads the columns
+// that one wave touches together over all banks (a wave-wide 8-byte access
+// then costs the two LDS cycles its 512 bytes need instead of 4..16).
+__device__ __forceinline__ int zb_slot(int x, int y)
+{
+    return (x << TILE_LOG) + (y ^ (int)(__brev((unsigned)x) >> 27));
+}
+
+// Work split: each wave takes chunks of 16 bin entries; an entry is cut into
+// strips of 16 rows, and each quarter of the wave (16 lanes = 16 rows) walks
+// the columns of one strip, so 4 strips are rasterised per LDS instruction and
+// the per-entry bookkeeping is vector work shared by 4 entries.
 // WRITE_IDMAP: store winner + 1 (0 = empty) of every pixel to idmap[v][x][y]
 // (non-exact output).  Otherwise mark seen[v][winner] = 1 (exact mode).
 template <bool WRITE_IDMAP>
@@ -156,32 +227,42 @@ __global__ __launch_bounds__(256) void tile_zbuffer_kernel(
     __syncthreads();
 
     const int lane = tid & 63, wave = tid >> 6;
-    for (i64 base = begin + (i64)wave * 64; base < end; base += 4 * 64) {
-        const int n = (int)((end - base) < 64 ? (end - base) : 64);
-        unsigned k_lo = 0, k_hi = 0, bx = 0, by = 0;
-        if (lane < n) {
-            const uint4 raw = *(const uint4 *)(entries + base + lane);
-            k_lo = raw.x; k_hi = raw.y; bx = raw.z; by = raw.w;
+    const int q = lane >> 4, ly = lane & 15;
+    for (i64 base = begin + (i64)wave * 16; base < end; base += 4 * 16) {
+        const int n = (int)((end - base) < 16 ? (end - base) : 16);
+        // every quarter holds the same 16 entries, one per lane of the quarter
+        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+        if (ly < n) raw = *(const uint4 *)(entries + base + ly);
+        int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
+        int ya = (int)(raw.w & 0xffffu) - y0, yb = (int)(raw.w >> 16) - y0;
+        xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+        xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
+        const int ns = (ly < n && yb > ya && xb > xa) ? (yb - ya + 15) >> 4 : 0;   // strips of this entry
+        int inc = ns;                                                           // inclusive scan in the quarter
+#pragma unroll
+        for (int dlt = 1; dlt < 16; dlt <<= 1) {
+            const int o = __shfl_up(inc, dlt, 16);
+            if (ly >= dlt) inc += o;
         }
-        for (int j = 0; j < n; ++j) {
-            const unsigned s_lo = __builtin_amdgcn_readlane(k_lo, j);
-            const unsigned s_hi = __builtin_amdgcn_readlane(k_hi, j);
-            const unsigned s_bx = __builtin_amdgcn_readlane(bx, j);
-            const unsigned s_by = __builtin_amdgcn_readlane(by, j);
-            const u64 key = ((u64)s_hi << 32) | s_lo;
-            int xa = (int)(s_bx & 0xffffu) - x0, xb = (int)(s_bx >> 16) - x0;
-            int ya = (int)(s_by & 0xffffu) - y0, yb = (int)(s_by >> 16) - y0;
-            xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
-            xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
-            const int h = yb - ya;
-            if (h <= 0 || xb <= xa) continue;
-            // lanes cover hh (>= h, power of two) rows x 64/hh columns per step
-            const int hlog = h <= 1 ? 0 : 32 - __clz(h - 1);
-            const int ly = lane & ((1 << hlog) - 1), lx = lane >> hlog;
-            const int step = 64 >> hlog;
-            if (ly < h) {
-                u64 *col = zb + ya + ly;
-                for (int x = xa + lx; x < xb; x += step) atomicMin(&col[x << TILE_LOG], key);
+        const int total = __shfl(inc, 15, 16);
+        const unsigned box = (unsigned)xa | ((unsigned)xb << 8) | ((unsigned)ya << 16) | ((unsigned)yb << 24);
+        const int first = inc - ns;
+        for (int s0 = 0; s0 < total; s0 += 4) {
+            const int st = s0 + q;                                   // strip of this quarter
+            const u64 bal = __ballot(inc <= st);
+            const int owner = __popc((unsigned)(bal >> (q << 4)) & 0xffffu) & 15;
+            const int src_lane = (q << 4) | owner;
+            const unsigned klo = __shfl(raw.x, src_lane), khi = __shfl(raw.y, src_lane);
+            const unsigned ebox = __shfl(box, src_lane);
+            const int efirst = __shfl(first, src_lane);
+            if (st < total) {
+                const int exa = ebox & 0xffu, exb = (ebox >> 8) & 0xffu;
+                const int eya = (ebox >> 16) & 0xffu, eyb = ebox >> 24;
+                const int yy = eya + ((st - efirst) << 4) + ly;
+                if (yy < eyb) {
+                    const u64 key = ((u64)khi << 32) | klo;
+                    for (int x = exa; x < exb; ++x) atomicMin(&zb[zb_slot(x, yy)], key);
+                }
             }
         }
     }
@@ -190,21 +271,23 @@ __global__ __launch_bounds__(256) void tile_zbuffer_kernel(
     if (WRITE_IDMAP) {
         unsigned *im = idmap + (size_t)v * W * Hc;
         for (int p = tid; p < TILE * TILE; p += 256) {
-            const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
+            const int lx = p >> TILE_LOG, lyy = p & (TILE - 1);
+            const int gx = x0 + lx, gy = y0 + lyy;
             if (gx < W && gy < Hc) {
-                const u64 key = zb[p];
+                const u64 key = zb[zb_slot(lx, lyy)];
                 im[(size_t)gx * Hc + gy] = key == ZB_EMPTY ? 0u : (unsigned)key + 1u;
             }
         }
     } else {
         uint8_t *sv = seen + (size_t)v * seen_stride;
         for (int p = tid; p < TILE * TILE; p += 256) {
-            const u64 key = zb[p];
+            const int lx = p >> TILE_LOG, lyy = p & (TILE - 1);
+            const u64 key = zb[zb_slot(lx, lyy)];
             if (key == ZB_EMPTY) continue;
             const unsigned w = (unsigned)key;
             // one store per vertical run of the same winner
-            if ((p & (TILE - 1)) != 0) {
-                const u64 up = zb[p - 1];
+            if (lyy != 0) {
+                const u64 up = zb[zb_slot(lx, lyy - 1)];
                 if (up != ZB_EMPTY && (unsigned)up == w) continue;
             }
             sv[w] = 1;
@@ -342,65 +425,122 @@ __device__ __forceinline__ int mi_survives(
     return 2;
 }
 
-__global__ __launch_bounds__(256) void mi_point_count_kernel(
+// Pixel, distance and y_proj of a kept (point, view) mapping (no visibility
+// re-check: the caller holds the kept-view mask).
+__device__ __forceinline__ void mi_pixel(
+    const CloudSrc &src, const mvf_vis_params &P, const PixelXform &X, i64 i, int v,
+    int &px, int &py, float &dist, double &y_proj)
+{
+    double x, y; float fx, fy;
+    src.get(i, v, P, x, y, dist, fx, fy);
+    px = ((int)x / X.up - src.views[v].crop_off_x) / X.down;
+    py = ((int)y / X.up - src.views[v].crop_off_y) / X.down;
+    y_proj = y;
+}
+
+// Pass 1 of the CSR assembly: one thread per output point id.  Gathers the
+// seen flags of its point over all views (independent loads first), resolves
+// centre-pixel conflicts and the crop, stores the kept-view bit masks
+// masks[word][q] and the block's mapping count.
+__global__ __launch_bounds__(256) void mi_point_mask_kernel(
     CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
     const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
-    const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ cnt,
-    int *__restrict__ view_seen)
+    const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
+    unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (q >= num_points) return;
-    const i64 i = inv_ids[q];
+    const i64 i = q < num_points ? inv_ids[q] : -1;
     unsigned c = 0;
-    if (i >= 0) {
-        for (int v = 0; v < V; ++v) {
+    const int words = (V + 31) >> 5;
+    for (int wd = 0; wd < words; ++wd) {
+        unsigned sm = 0;
+        if (i >= 0) {
+            const int vend = V - (wd << 5) < 32 ? V - (wd << 5) : 32;
+            const uint8_t *sp = seen + (size_t)(wd << 5) * src.n + i;
+#pragma unroll 8
+            for (int bit = 0; bit < vend; ++bit) sm |= (sp[(size_t)bit * src.n] ? 1u : 0u) << bit;
+        }
+        unsigned kept = 0;
+        while (sm) {
+            const int bit = __ffs(sm) - 1;
+            sm &= sm - 1;
+            const int v = (wd << 5) + bit;
             int px, py; float d; double yp;
             const int s = mi_survives(src, P, seen, Hc, centre_ws, epoch, X, i, v, px, py, d, yp);
             if (s) view_seen[v] = 1;
-            if (s == 2) ++c;
+            if (s == 2) kept |= 1u << bit;
         }
+        if (q < num_points) masks[(size_t)wd * num_points + q] = kept;
+        c += __popc(kept);
     }
-    cnt[q] = c;
+    unsigned total;
+    block_exclusive_scan<unsigned>(c, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// rank of each seen view among the seen views (lexunique + bucketize,
-// image.py:392-394); V is small: one wave, serial.
-__global__ void mi_view_rank_kernel(const int *__restrict__ view_seen, int V, int *__restrict__ view_rank,
-                                    i64 *__restrict__ n_seen_out)
+// Pass 2 (one block): exclusive scan of the block counts, grand total, and
+// the rank of each seen view among the seen views (lexunique + bucketize,
+// image.py:392-394).
+__global__ __launch_bounds__(1024) void mi_spine_kernel(
+    const unsigned *__restrict__ block_sums, i64 nb, i64 *__restrict__ block_off,
+    i64 *__restrict__ pointers_end, i64 *__restrict__ counters,
+    const int *__restrict__ view_seen, int V, int *__restrict__ view_rank)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int r = 0;
-    for (int v = 0; v < V; ++v) { view_rank[v] = r; r += view_seen[v] ? 1 : 0; }
-    *n_seen_out = r;
+    const i64 per = (nb + 1023) / 1024;
+    const i64 lo = (i64)threadIdx.x * per;
+    const i64 hi = lo + per < nb ? lo + per : nb;
+    i64 s = 0;
+    for (i64 k = lo; k < hi; ++k) s += block_sums[k];
+    i64 total;
+    i64 run = block_exclusive_scan<i64, 16>(s, total);
+    for (i64 k = lo; k < hi; ++k) { block_off[k] = run; run += block_sums[k]; }
+    if (threadIdx.x == 0) {
+        *pointers_end = total;
+        counters[0] = total;
+        int r = 0;
+        for (int v = 0; v < V; ++v) { view_rank[v] = r; r += view_seen[v] ? 1 : 0; }
+        counters[3] = r;
+    }
 }
 
+// Pass 3: pointers + images / pixels / features of every kept mapping, views
+// ascending inside a point.
 __global__ __launch_bounds__(256) void mi_fill_kernel(
-    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
-    const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
-    const i64 *__restrict__ inv_ids, i64 num_points, const i64 *__restrict__ pointers,
+    CloudSrc src, mvf_vis_params P, PixelXform X, int V, const i64 *__restrict__ inv_ids,
+    i64 num_points, const unsigned *__restrict__ masks, const i64 *__restrict__ block_off,
     const int *__restrict__ view_rank, FeatArgs A, i64 out_capacity,
-    i64 *__restrict__ images, int16_t *__restrict__ pixels, float *__restrict__ features,
-    i64 *__restrict__ overflow)
+    i64 *__restrict__ pointers, i64 *__restrict__ images, int16_t *__restrict__ pixels,
+    float *__restrict__ features, i64 *__restrict__ overflow)
 {
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    const int words = (V + 31) >> 5;
+    unsigned c = 0;
+    if (q < num_points)
+        for (int wd = 0; wd < words; ++wd) c += __popc(masks[(size_t)wd * num_points + q]);
+    unsigned total;
+    i64 k = block_off[blockIdx.x] + block_exclusive_scan<unsigned>(c, total);
     if (q >= num_points) return;
+    pointers[q] = k;
+    if (c == 0) return;
     const i64 i = inv_ids[q];
-    if (i < 0) return;
-    i64 k = pointers[q];
-    if (pointers[q + 1] == k) return;
     const float px3 = src.xyz[3 * i], py3 = src.xyz[3 * i + 1], pz3 = src.xyz[3 * i + 2];
-    for (int v = 0; v < V; ++v) {
-        int px, py; float d; double yp;
-        if (mi_survives(src, P, seen, Hc, centre_ws, epoch, X, i, v, px, py, d, yp) != 2) continue;
-        if (k < out_capacity) {
-            images[k] = view_rank[v];
-            pixels[2 * k] = (int16_t)px; pixels[2 * k + 1] = (int16_t)py;
-            write_features(features + (size_t)k * A.F, A, i, px3, py3, pz3,
-                           src.views[v].img_xyz, d, yp);
-        } else {
-            *overflow = 1;
+    for (int wd = 0; wd < words; ++wd) {
+        unsigned m = masks[(size_t)wd * num_points + q];
+        while (m) {
+            const int v = (wd << 5) + __ffs(m) - 1;
+            m &= m - 1;
+            if (k < out_capacity) {
+                int px, py; float d; double yp;
+                mi_pixel(src, P, X, i, v, px, py, d, yp);
+                images[k] = view_rank[v];
+                pixels[2 * k] = (int16_t)px; pixels[2 * k + 1] = (int16_t)py;
+                write_features(features + (size_t)k * A.F, A, i, px3, py3, pz3,
+                               src.views[v].img_xyz, d, yp);
+            } else {
+                *overflow = 1;
+            }
+            ++k;
         }
-        ++k;
     }
 }
 
@@ -463,7 +603,6 @@ extern "C" size_t mvf_splat_visibility_workspace_bytes(
     const size_t npix = (size_t)W * H;
     size_t b = 0;
     b += align_up((tiles + 1) * sizeof(unsigned)) * 3;                // count, off, cur
-    b += align_up(scan_workspace_elems(tiles) * sizeof(unsigned));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)(m > 0 ? m : 1));                           // seen
     b += align_up(npix * sizeof(unsigned));                           // idmap
@@ -493,7 +632,6 @@ extern "C" int mvf_splat_visibility(
     unsigned *tile_count = ar.take<unsigned>(tiles + 1);
     unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
     unsigned *tile_off = ar.take<unsigned>(tiles + 1);
-    unsigned *scan_ws = ar.take<unsigned>(scan_workspace_elems(tiles));
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>(m);
     unsigned *idmap = ar.take<unsigned>(npix);
@@ -510,11 +648,24 @@ extern "C" int mvf_splat_visibility(
 
     ArraySrc src{x_proj, y_proj, dist, fx, fy, (i64)m};
     dim3 grid_m(cdiv(m, 256), 1), block(256);
-    hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false>), grid_m, block, 0, st, src, P, tiles_y,
-                       (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0);
-    exclusive_scan<unsigned, unsigned, i64>(tile_count, tiles, tile_off, scan_ws, (i64 *)counters + 1, st);
-    hipLaunchKernelGGL((bin_fill_kernel<ArraySrc>), grid_m, block, 0, st, src, P, tiles_y, (int)tiles,
-                       tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
+    if (tiles <= BIN_MAX_TILES)
+        hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, true>), grid_m, block,
+                           (size_t)tiles * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
+                           tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0);
+    else
+        hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, false>), grid_m, block, 0, st, src, P,
+                           tiles_y, (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0,
+                           (i64 *)nullptr, (int *)nullptr, 0);
+    hipLaunchKernelGGL((scan_single_block_kernel<unsigned, unsigned, i64>), dim3(1), dim3(1024), 0, st,
+                       tile_count, tiles, tile_off, (i64 *)counters + 1);
+    if (tiles <= BIN_MAX_TILES)
+        hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, true>), grid_m, block,
+                           2 * (size_t)tiles * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
+                           tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
+    else
+        hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, false>), grid_m, block, 0, st, src, P, tiles_y,
+                           (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity,
+                           (i64 *)counters + 2);
     if (P.exact) {
         hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
                            tile_off, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc, seen, (i64)m,
@@ -588,14 +739,16 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
 {
     const size_t tiles = (size_t)V * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
+    const size_t words = (size_t)(V + 31) / 32;
     size_t b = 0;
-    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;
-    b += align_up(scan_workspace_elems(tiles) * sizeof(unsigned));
+    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;                           // count, cur, off
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)V * (size_t)(n > 0 ? n : 1));                          // seen
-    b += align_up((size_t)(num_points + 1) * sizeof(unsigned));                  // cnt
-    b += align_up(scan_workspace_elems(num_points) * sizeof(i64));
-    b += align_up((size_t)V * sizeof(int)) * 1;                                  // view_rank
+    b += align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned));  // masks
+    b += align_up(nb * sizeof(unsigned));                                        // block sums
+    b += align_up(nb * sizeof(i64));                                             // block offsets
+    b += align_up((size_t)V * sizeof(int));                                      // view_rank
     return b;
 }
 
@@ -623,35 +776,49 @@ extern "C" int mvf_map_images_exact(
     tile_grid(P, tiles_x, tiles_y, Hc);
     const int tiles_per_view = tiles_x * tiles_y;
     const i64 tiles = (i64)tiles_per_view * V;
+    const i64 nb = cdiv(num_points, 256);
+    const int words = (V + 31) / 32;
 
     Arena ar(workspace, workspace_bytes);
     unsigned *tile_count = ar.take<unsigned>(tiles + 1);
     unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
     unsigned *tile_off = ar.take<unsigned>(tiles + 1);
-    unsigned *scan_ws = ar.take<unsigned>(scan_workspace_elems(tiles));
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>((size_t)V * n);
-    unsigned *cnt = ar.take<unsigned>(num_points + 1);
-    i64 *scan_ws64 = ar.take<i64>(scan_workspace_elems(num_points));
+    unsigned *masks = ar.take<unsigned>((size_t)words * num_points);
+    unsigned *block_sums = ar.take<unsigned>(nb);
+    i64 *block_off = ar.take<i64>(nb);
     int *view_rank = ar.take<int>(V);
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
     MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
-    MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
-    MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int), st));
+    prof_mark("memset", st);
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
-    prof_mark("memset", st);
-    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true>), grid_nv, block, 0, st, src, P, tiles_y,
-                       tiles_per_view, tile_count, seen, (i64)n);
+    const bool lds_bins = tiles_per_view <= BIN_MAX_TILES;
+    if (lds_bins)
+        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, true>), grid_nv, block,
+                           (size_t)tiles_per_view * sizeof(unsigned), st, src, P, tiles_y,
+                           tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters, view_seen, V);
+    else
+        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, false>), grid_nv, block, 0, st, src, P,
+                           tiles_y, tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters,
+                           view_seen, V);
     prof_mark("bin_count", st);
-    exclusive_scan<unsigned, unsigned, i64>(tile_count, tiles, tile_off, scan_ws, (i64 *)counters + 1, st);
+    hipLaunchKernelGGL((scan_single_block_kernel<unsigned, unsigned, i64>), dim3(1), dim3(1024), 0, st,
+                       tile_count, tiles, tile_off, (i64 *)counters + 1);
     prof_mark("tile_scan", st);
-    hipLaunchKernelGGL((bin_fill_kernel<CloudSrc>), grid_nv, block, 0, st, src, P, tiles_y,
-                       tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
-                       (i64 *)counters + 2);
+    if (lds_bins)
+        hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, true>), grid_nv, block,
+                           2 * (size_t)tiles_per_view * sizeof(unsigned), st, src, P, tiles_y,
+                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
+                           (i64 *)counters + 2);
+    else
+        hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, false>), grid_nv, block, 0, st, src, P, tiles_y,
+                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
+                           (i64 *)counters + 2);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
                        tile_off, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc, seen, (i64)n,
@@ -661,19 +828,19 @@ extern "C" int mvf_map_images_exact(
     prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
-    dim3 grid_q(cdiv(num_points, 256));
-    hipLaunchKernelGGL(mi_point_count_kernel, grid_q, block, 0, st, src, P, seen, Hc,
-                       (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points, cnt,
-                       view_seen);
-    prof_mark("point_count", st);
-    exclusive_scan<unsigned, i64, i64>(cnt, num_points, (i64 *)pointers, scan_ws64, (i64 *)counters, st);
-    prof_mark("point_scan", st);
-    hipLaunchKernelGGL(mi_view_rank_kernel, dim3(1), dim3(64), 0, st, view_seen, V, view_rank,
-                       (i64 *)counters + 3);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, 0, st, src, P, seen, Hc, (const u64 *)centre_ws,
-                       epoch, X, V, (const i64 *)inv_ids, (i64)num_points, (const i64 *)pointers,
-                       view_rank, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
-                       (i64)out_capacity, (i64 *)images, pixels, features, (i64 *)counters + 2);
+    dim3 grid_q((unsigned)nb);
+    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, 0, st, src, P, seen, Hc,
+                       (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points,
+                       masks, block_sums, view_seen);
+    prof_mark("point_mask", st);
+    hipLaunchKernelGGL(mi_spine_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, block_off,
+                       (i64 *)pointers + num_points, (i64 *)counters, view_seen, V, view_rank);
+    prof_mark("spine", st);
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, 0, st, src, P, X, V, (const i64 *)inv_ids,
+                       (i64)num_points, masks, block_off, view_rank,
+                       feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
+                       (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
+                       (i64 *)counters + 2);
     prof_mark("csr_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;

@@ -33,11 +33,11 @@ __device__ __forceinline__ unsigned block_rank_flag(bool flag, unsigned &total)
     return off + below;
 }
 
-// Block-wide exclusive scan of one value per thread (256 threads).
-template <typename T>
+// Block-wide exclusive scan of one value per thread (NW waves of 64 threads).
+template <typename T, int NW = 4>
 __device__ __forceinline__ T block_exclusive_scan(T v, T &total)
 {
-    __shared__ T wave_sum[4];
+    __shared__ T wave_sum[NW];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T inc = v;
 #pragma unroll
@@ -49,7 +49,7 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T &total)
     __syncthreads();
     T off = 0, tot = 0;
 #pragma unroll
-    for (unsigned w = 0; w < 4; ++w) {
+    for (unsigned w = 0; w < NW; ++w) {
         const T c = wave_sum[w];
         if (w < wave) off += c;
         tot += c;
@@ -57,6 +57,31 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T &total)
     __syncthreads();
     total = tot;
     return off + inc - v;
+}
+
+// ---- single-launch scan for small arrays (tile counters, block sums) --------
+// One 1024-thread block; thread t owns the contiguous chunk [t*per, (t+1)*per).
+// out[i] = sum(in[0..i)), out[n] = total; in == out is allowed.
+template <typename TI, typename TO, typename TT>
+__global__ __launch_bounds__(1024) void scan_single_block_kernel(
+    const TI *in, i64 n, TO *out, TT *__restrict__ total_out)
+{
+    const i64 per = (n + 1023) / 1024;
+    const i64 lo = (i64)threadIdx.x * per;
+    const i64 hi = lo + per < n ? lo + per : n;
+    TO s = 0;
+    for (i64 i = lo; i < hi; ++i) s += (TO)in[i];
+    TO total;
+    TO run = block_exclusive_scan<TO, 16>(s, total);
+    for (i64 i = lo; i < hi; ++i) {
+        const TO v = (TO)in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) {
+        out[n] = total;
+        if (total_out) *total_out = (TT)total;
+    }
 }
 
 // ---- 3-kernel exclusive scan: out[i] = sum(in[0..i)), out[n] = total --------
