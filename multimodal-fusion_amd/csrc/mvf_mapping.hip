@@ -181,18 +181,54 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 // ------------------------------------------------------------------------- //
 // z-buffer of one tile in LDS                                                 //
 // ------------------------------------------------------------------------- //
-// LDS image: zb[x][y ^ bitrev5(x)], 8-byte keys.  The XOR spreads the columns
-// that one wave touches together over all banks (a wave-wide 8-byte access
-// then costs the two LDS cycles its 512 bytes need instead of 4..16).
-__device__ __forceinline__ int zb_slot(int x, int y)
+// LDS image: zb[x][y], 8-byte keys, y fastest.
+//
+// Work split.  The 256 threads form 16 "quarters" (rows of 16 lanes).  The bin
+// is consumed 256 entries at a time: entry e of such a group belongs to
+// quarter e % 16 and sits in lane e / 16 of that quarter, so every quarter
+// gets the same number of entries (+-1) whatever the bin size.  A quarter
+// walks its entries one after the other: the entry's key and clipped box are
+// broadcast inside the row with DPP (row_newbcast, no LDS traffic), its 16
+// lanes cover 16 consecutive rows y and loop over the columns x, one LDS
+// atomicMin per covered pixel.  The four quarters of a wave run different
+// entries in the same instruction stream.
+template <int J> __device__ __forceinline__ unsigned row_bcast(unsigned v)
 {
-    return (x << TILE_LOG) + (y ^ (int)(__brev((unsigned)x) >> 27));
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xf, 0xf, false);
 }
 
-// Work split: each wave takes chunks of 16 bin entries; an entry is cut into
-// strips of 16 rows, and each quarter of the wave (16 lanes = 16 rows) walks
-// the columns of one strip, so 4 strips are rasterised per LDS instruction and
-// the per-entry bookkeeping is vector work shared by 4 entries.
+template <int J>
+__device__ __forceinline__ void raster_entry(u64 *zb, unsigned klo, unsigned khi, unsigned box, int ly)
+{
+    const unsigned eklo = row_bcast<J>(klo), ekhi = row_bcast<J>(khi), ebox = row_bcast<J>(box);
+    const int exa = ebox & 0x7fu, exb = (ebox >> 8) & 0x7fu;
+    const int eya = (ebox >> 16) & 0x7fu, eyb = ebox >> 24;
+    const u64 key = ((u64)ekhi << 32) | eklo;
+    for (int yy = eya + ly; yy < eyb; yy += 16) {
+        u64 *p = zb + (exa << TILE_LOG) + yy;
+        int x = exa;
+        for (; x + 4 <= exb; x += 4, p += 4 * TILE) {
+            atomicMin(p, key);
+            atomicMin(p + TILE, key);
+            atomicMin(p + 2 * TILE, key);
+            atomicMin(p + 3 * TILE, key);
+        }
+        for (; x < exb; ++x, p += TILE) atomicMin(p, key);
+    }
+}
+
+// Clipped box of a bin entry relative to the tile, packed 4 x 8 bits
+// (xa, xb, ya, yb <= 64); 0 when the entry is absent or misses the tile.
+__device__ __forceinline__ unsigned clip_box(const uint4 &raw, int x0, int y0, bool valid)
+{
+    int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
+    int ya = (int)(raw.w & 0xffffu) - y0, yb = (int)(raw.w >> 16) - y0;
+    xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
+    xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
+    if (!valid || xb <= xa || yb <= ya) return 0u;
+    return (unsigned)xa | ((unsigned)xb << 8) | ((unsigned)ya << 16) | ((unsigned)yb << 24);
+}
+
 // WRITE_IDMAP: store winner + 1 (0 = empty) of every pixel to idmap[v][x][y]
 // (non-exact output).  Otherwise mark seen[v][winner] = 1 (exact mode).
 template <bool WRITE_IDMAP>
@@ -223,71 +259,50 @@ __global__ __launch_bounds__(256) void tile_zbuffer_kernel(
         return;
     }
 
+    const int ly = tid & 15;
+    const int slot = ly * 16 + (tid >> 4);        // entry of this lane inside a group of 256
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+    if (begin + slot < end) raw = *(const uint4 *)(entries + begin + slot);
+
     for (int p = tid; p < TILE * TILE; p += 256) zb[p] = ZB_EMPTY;
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
-    const int q = lane >> 4, ly = lane & 15;
-    for (i64 base = begin + (i64)wave * 16; base < end; base += 4 * 16) {
-        const int n = (int)((end - base) < 16 ? (end - base) : 16);
-        // every quarter holds the same 16 entries, one per lane of the quarter
-        uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-        if (ly < n) raw = *(const uint4 *)(entries + base + ly);
-        int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
-        int ya = (int)(raw.w & 0xffffu) - y0, yb = (int)(raw.w >> 16) - y0;
-        xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
-        xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
-        const int ns = (ly < n && yb > ya && xb > xa) ? (yb - ya + 15) >> 4 : 0;   // strips of this entry
-        int inc = ns;                                                           // inclusive scan in the quarter
-#pragma unroll
-        for (int dlt = 1; dlt < 16; dlt <<= 1) {
-            const int o = __shfl_up(inc, dlt, 16);
-            if (ly >= dlt) inc += o;
-        }
-        const int total = __shfl(inc, 15, 16);
-        const unsigned box = (unsigned)xa | ((unsigned)xb << 8) | ((unsigned)ya << 16) | ((unsigned)yb << 24);
-        const int first = inc - ns;
-        for (int s0 = 0; s0 < total; s0 += 4) {
-            const int st = s0 + q;                                   // strip of this quarter
-            const u64 bal = __ballot(inc <= st);
-            const int owner = __popc((unsigned)(bal >> (q << 4)) & 0xffffu) & 15;
-            const int src_lane = (q << 4) | owner;
-            const unsigned klo = __shfl(raw.x, src_lane), khi = __shfl(raw.y, src_lane);
-            const unsigned ebox = __shfl(box, src_lane);
-            const int efirst = __shfl(first, src_lane);
-            if (st < total) {
-                const int exa = ebox & 0xffu, exb = (ebox >> 8) & 0xffu;
-                const int eya = (ebox >> 16) & 0xffu, eyb = ebox >> 24;
-                const int yy = eya + ((st - efirst) << 4) + ly;
-                if (yy < eyb) {
-                    const u64 key = ((u64)khi << 32) | klo;
-                    for (int x = exa; x < exb; ++x) atomicMin(&zb[zb_slot(x, yy)], key);
-                }
-            }
-        }
+    for (i64 base = begin; base < end; base += 256) {
+        const i64 rem = end - base;
+        // prefetch the next group while this one is rasterised
+        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+        if (base + 256 + slot < end) nxt = *(const uint4 *)(entries + base + 256 + slot);
+        const unsigned box = clip_box(raw, x0, y0, slot < rem);
+        const unsigned klo = raw.x, khi = raw.y;
+        const int maxj = rem >= 256 ? 16 : (int)((rem + 15) >> 4);   // lanes in use per quarter
+#define MVF_RASTER(J) if (J < maxj) raster_entry<J>(zb, klo, khi, box, ly);
+        MVF_RASTER(0) MVF_RASTER(1) MVF_RASTER(2) MVF_RASTER(3)
+        MVF_RASTER(4) MVF_RASTER(5) MVF_RASTER(6) MVF_RASTER(7)
+        MVF_RASTER(8) MVF_RASTER(9) MVF_RASTER(10) MVF_RASTER(11)
+        MVF_RASTER(12) MVF_RASTER(13) MVF_RASTER(14) MVF_RASTER(15)
+#undef MVF_RASTER
+        raw = nxt;
     }
     __syncthreads();
 
     if (WRITE_IDMAP) {
         unsigned *im = idmap + (size_t)v * W * Hc;
         for (int p = tid; p < TILE * TILE; p += 256) {
-            const int lx = p >> TILE_LOG, lyy = p & (TILE - 1);
-            const int gx = x0 + lx, gy = y0 + lyy;
+            const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
             if (gx < W && gy < Hc) {
-                const u64 key = zb[zb_slot(lx, lyy)];
+                const u64 key = zb[p];
                 im[(size_t)gx * Hc + gy] = key == ZB_EMPTY ? 0u : (unsigned)key + 1u;
             }
         }
     } else {
         uint8_t *sv = seen + (size_t)v * seen_stride;
         for (int p = tid; p < TILE * TILE; p += 256) {
-            const int lx = p >> TILE_LOG, lyy = p & (TILE - 1);
-            const u64 key = zb[zb_slot(lx, lyy)];
+            const u64 key = zb[p];
             if (key == ZB_EMPTY) continue;
             const unsigned w = (unsigned)key;
             // one store per vertical run of the same winner
-            if (lyy != 0) {
-                const u64 up = zb[zb_slot(lx, lyy - 1)];
+            if ((p & (TILE - 1)) != 0) {
+                const u64 up = zb[p - 1];
                 if (up != ZB_EMPTY && (unsigned)up == w) continue;
             }
             sv[w] = 1;
