@@ -77,9 +77,27 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
 // points of a block touch few tiles.  Tile counters are therefore first
 // accumulated in an LDS histogram of the view's tiles and flushed with one
 // global atomic per touched tile: global atomics on the hot tile counters
-// otherwise serialise at the memory side.  Views with more than BIN_MAX_TILES
-// tiles use global atomics directly (USE_LDS = false).
-constexpr int BIN_MAX_TILES = 4096;
+// otherwise serialise at the memory side.  Views whose counters do not fit the
+// LDS histogram use global atomics directly (USE_LDS = false).
+//
+// Inside a tile the entries are grouped by decreasing clipped pixel count
+// (NCLS size classes, a factor 2 apart): the z-buffer kernel deals consecutive
+// entries to lanes that share an instruction stream, and entries of similar
+// size keep those lanes busy for the same number of steps.  Counters are
+// therefore indexed [view][tile][class].
+constexpr int NCLS = 8;
+constexpr int BIN_MAX_COUNTERS = 12288;      // LDS histogram entries per block (48 KB)
+
+// Size class of a (splat, tile) pair: 0 = largest.
+__device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
+{
+    const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
+    const int cw = (b.xb < x0 + TILE ? b.xb : x0 + TILE) - (b.xa > x0 ? b.xa : x0);
+    const int ch = (b.yb < y0 + TILE ? b.yb : y0 + TILE) - (b.ya > y0 ? b.ya : y0);
+    const int l = 31 - __clz(cw * ch);              // area >= 1
+    const int c = l < 3 ? 0 : (l > 9 ? 7 : l - 2);
+    return (NCLS - 1) - c;
+}
 
 template <class Src, bool ZERO_SEEN, bool USE_LDS>
 __global__ __launch_bounds__(256) void bin_count_kernel(
@@ -98,28 +116,31 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     }
     const bool live = i < src.count();
     if (ZERO_SEEN && live) seen[(size_t)v * seen_stride + i] = 0;
-    double x, y; float d, fx, fy;
+    double x, y; float d = 0.f, fx, fy;
     const bool have = live && src.get(i, v, P, x, y, d, fx, fy);
     BBox b{0, 0, 0, 0};
     if (have) b = splat_bbox(x, y, d, fx, fy, P);
     const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
-    unsigned *tc = tile_count + (size_t)v * tiles_per_view;
+    const int ncnt = tiles_per_view * NCLS;
+    unsigned *tc = tile_count + (size_t)v * ncnt;
     if (USE_LDS) {
         if (!__syncthreads_or(have)) return;
-        for (int t = tid; t < tiles_per_view; t += 256) hist[t] = 0;
+        for (int t = tid; t < ncnt; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
-                for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&hist[tx * tiles_y + ty], 1u);
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
         __syncthreads();
-        for (int t = tid; t < tiles_per_view; t += 256) {
+        for (int t = tid; t < ncnt; t += 256) {
             const unsigned c = hist[t];
             if (c) atomicAdd(&tc[t], c);
         }
     } else if (have) {
         for (int tx = tx0; tx <= tx1; ++tx)
-            for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&tc[tx * tiles_y + ty], 1u);
+            for (int ty = ty0; ty <= ty1; ++ty)
+                atomicAdd(&tc[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
     }
 }
 
@@ -129,7 +150,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
     TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
 {
-    extern __shared__ unsigned hist[];          // [tiles_per_view] counts, then [tiles_per_view] bases
+    extern __shared__ unsigned hist[];   // per (tile, class): count, then absolute write cursor
     const int tid = threadIdx.x;
     const i64 i = (i64)blockIdx.x * 256 + tid;
     const int v = blockIdx.y;
@@ -142,35 +163,35 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     TileEntry e;
     e.key = depth_key(d, (unsigned)i);
     e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
-    const size_t tbase = (size_t)v * tiles_per_view;
+    const int ncnt = tiles_per_view * NCLS;
+    const size_t cbase = (size_t)v * ncnt;
     if (USE_LDS) {
         if (!__syncthreads_or(have)) return;
-        unsigned *base = hist + tiles_per_view;
-        for (int t = tid; t < tiles_per_view; t += 256) hist[t] = 0;
+        for (int t = tid; t < ncnt; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
-                for (int ty = ty0; ty <= ty1; ++ty) atomicAdd(&hist[tx * tiles_y + ty], 1u);
+                for (int ty = ty0; ty <= ty1; ++ty)
+                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
         __syncthreads();
-        // one global reservation per touched tile; hist becomes the local cursor
-        for (int t = tid; t < tiles_per_view; t += 256) {
+        // one global reservation per touched counter; hist becomes the write cursor
+        for (int t = tid; t < ncnt; t += 256) {
             const unsigned c = hist[t];
-            if (c) base[t] = atomicAdd(&tile_cur[tbase + t], c);
-            hist[t] = 0;
+            if (c) hist[t] = tile_off[cbase + t] + atomicAdd(&tile_cur[cbase + t], c);
         }
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
                 for (int ty = ty0; ty <= ty1; ++ty) {
-                    const int t = tx * tiles_y + ty;
-                    const i64 pos = (i64)tile_off[tbase + t] + base[t] + atomicAdd(&hist[t], 1u);
+                    const int t = (tx * tiles_y + ty) * NCLS + size_class(b, tx, ty);
+                    const i64 pos = (i64)atomicAdd(&hist[t], 1u);
                     if (pos < pair_capacity) entries[pos] = e;
                     else *overflow = 1;
                 }
     } else if (have) {
         for (int tx = tx0; tx <= tx1; ++tx)
             for (int ty = ty0; ty <= ty1; ++ty) {
-                const size_t t = tbase + tx * tiles_y + ty;
+                const size_t t = cbase + (tx * tiles_y + ty) * NCLS + size_class(b, tx, ty);
                 const i64 pos = (i64)tile_off[t] + atomicAdd(&tile_cur[t], 1u);
                 if (pos < pair_capacity) entries[pos] = e;
                 else *overflow = 1;
@@ -183,130 +204,217 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 // ------------------------------------------------------------------------- //
 // LDS image: zb[x][y], 8-byte keys, y fastest.
 //
-// Work split.  The 256 threads form 16 "quarters" (rows of 16 lanes).  The bin
-// is consumed 256 entries at a time: entry e of such a group belongs to
-// quarter e % 16 and sits in lane e / 16 of that quarter, so every quarter
-// gets the same number of entries (+-1) whatever the bin size.  A quarter
-// walks its entries one after the other: the entry's key and clipped box are
-// broadcast inside the row with DPP (row_newbcast, no LDS traffic), its 16
-// lanes cover 16 consecutive rows y and loop over the columns x, one LDS
-// atomicMin per covered pixel.  The four quarters of a wave run different
-// entries in the same instruction stream.
+// An LDS atomicMin costs the same whatever the number of active lanes
+// (measured on gfx950: about 6.3 cycles per wave-instruction per CU for 64-bit
+// keys), so the kernel is built to put as many covered pixels as possible in
+// every atomic instruction and to keep LDS waits out of the loop.  The 256
+// threads form 16 "quarters" (rows of 16 lanes).  The bin is consumed 256
+// entries at a time, 64 per wave, one entry per lane.  Each wave first orders
+// its 64 entries by decreasing pixel count (a counting sort on the size class
+// with wave ballots, one ds_permute per register), so that the four quarters
+// of the wave, which walk the ordered list four entries at a time in one
+// instruction stream, get entries of similar size.  A quarter takes its entry
+// from lane J of its row with a DPP row broadcast (no LDS traffic) and its 16
+// lanes sweep the entry's pixels 16 at a time in column-major order (pixel id
+// = x_off * h + y_off): a 5x5 splat takes 2 sweeps, a 50x50 one 157, all
+// lanes busy.
 template <int J> __device__ __forceinline__ unsigned row_bcast(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xf, 0xf, false);
 }
 
 template <int J>
-__device__ __forceinline__ void raster_entry(u64 *zb, unsigned klo, unsigned khi, unsigned box, int ly)
+__device__ __forceinline__ void raster_entry(u64 *zb, const uint4 &mine, unsigned ly)
 {
-    const unsigned eklo = row_bcast<J>(klo), ekhi = row_bcast<J>(khi), ebox = row_bcast<J>(box);
-    const int exa = ebox & 0x7fu, exb = (ebox >> 8) & 0x7fu;
-    const int eya = (ebox >> 16) & 0x7fu, eyb = ebox >> 24;
-    const u64 key = ((u64)ekhi << 32) | eklo;
-    for (int yy = eya + ly; yy < eyb; yy += 16) {
-        u64 *p = zb + (exa << TILE_LOG) + yy;
-        int x = exa;
-        for (; x + 4 <= exb; x += 4, p += 4 * TILE) {
-            atomicMin(p, key);
-            atomicMin(p + TILE, key);
-            atomicMin(p + 2 * TILE, key);
-            atomicMin(p + 3 * TILE, key);
-        }
-        for (; x < exb; ++x, p += TILE) atomicMin(p, key);
+    const unsigned rx = row_bcast<J>(mine.x), ry = row_bcast<J>(mine.y);
+    const unsigned rz = row_bcast<J>(mine.z), rw = row_bcast<J>(mine.w);
+    const unsigned h = rz >> 24;
+    const unsigned area = ((rz >> 8) & 0xffu) * h;              // 0 for a staged miss
+    const u64 key = ((u64)ry << 32) | rx;
+    const unsigned q16 = rw & 31u, r16 = (rw >> 5) & 127u;
+    unsigned xo = (ly * (rw >> 12)) >> 16;                      // ly / h
+    unsigned yo = ly - xo * h;
+    u64 *col = zb + ((rz & 0xffu) << TILE_LOG) + ((rz >> 16) & 0xffu);
+    for (unsigned pid = ly; pid < area; pid += 16u) {
+        atomicMin(col + (xo << TILE_LOG) + yo, key);
+        xo += q16; yo += r16;
+        if (yo >= h) { yo -= h; xo += 1u; }
     }
 }
 
-// Clipped box of a bin entry relative to the tile, packed 4 x 8 bits
-// (xa, xb, ya, yb <= 64); 0 when the entry is absent or misses the tile.
-__device__ __forceinline__ unsigned clip_box(const uint4 &raw, int x0, int y0, bool valid)
+// Staged entry: key, clipped box (xa | w << 8 | ya << 16 | h << 24, w = 0 when
+// the entry is absent or misses the tile) and the constants of the sweep:
+// 16 / h, 16 % h and ceil(65536 / h).
+__device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, bool valid)
 {
     int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
     int ya = (int)(raw.w & 0xffffu) - y0, yb = (int)(raw.w >> 16) - y0;
     xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
     xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
-    if (!valid || xb <= xa || yb <= ya) return 0u;
-    return (unsigned)xa | ((unsigned)xb << 8) | ((unsigned)ya << 16) | ((unsigned)yb << 24);
+    if (!valid || xb <= xa || yb <= ya) return make_uint4(0u, 0u, 0u, 0u);
+    const unsigned w = xb - xa, h = yb - ya;
+    const unsigned q16 = 16u / h, r16 = 16u - q16 * h, rcp = (65536u + h - 1u) / h;
+    return make_uint4(raw.x, raw.y, (unsigned)xa | (w << 8) | ((unsigned)ya << 16) | (h << 24),
+                      q16 | (r16 << 5) | (rcp << 12));
 }
 
-// WRITE_IDMAP: store winner + 1 (0 = empty) of every pixel to idmap[v][x][y]
-// (non-exact output).  Otherwise mark seen[v][winner] = 1 (exact mode).
+// Scan of the [tile][class] counters, one tile per thread: exclusive offsets,
+// grand total, and the list of non-empty tiles with their entry ranges, which
+// is what the z-buffer kernel iterates over.  Every 1024-thread block first
+// re-adds the counters of the tiles in front of it (a few hundred KB of L2
+// hits at most), so a single launch needs no inter-block ordering.  tile_cur
+// is cleared here for the fill pass.
+struct TileDesc { unsigned tile, begin, end, pad; };
+
+__device__ __forceinline__ u64 tile_weight(const unsigned *__restrict__ tile_count, i64 t)
+{
+    const uint4 a = *(const uint4 *)(tile_count + t * NCLS);
+    const uint4 b = *(const uint4 *)(tile_count + t * NCLS + 4);
+    const u64 c = (u64)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    return c | ((u64)(c != 0) << 40);          // entries in the low 40 bits, non-empty tiles above
+}
+
+__global__ __launch_bounds__(1024) void tile_scan_kernel(
+    const unsigned *__restrict__ tile_count, i64 ntiles, unsigned *__restrict__ tile_off,
+    unsigned *__restrict__ tile_cur, TileDesc *__restrict__ descs, unsigned *__restrict__ n_desc,
+    i64 *__restrict__ total_out)
+{
+    const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
+    u64 front = 0;
+    for (i64 p = threadIdx.x; p < (i64)blockIdx.x * 1024; p += 1024) front += tile_weight(tile_count, p);
+    uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+    if (t < ntiles) {
+        a = *(const uint4 *)(tile_count + t * NCLS);
+        b = *(const uint4 *)(tile_count + t * NCLS + 4);
+    }
+    const u64 own = t < ntiles ? tile_weight(tile_count, t) : 0;
+    u64 front_total, own_total;
+    block_exclusive_scan<u64, 16>(front, front_total);
+    const u64 ex = block_exclusive_scan<u64, 16>(own, own_total) + front_total;
+    if (t < ntiles) {
+        const unsigned c[NCLS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned run = (unsigned)(ex & 0xffffffffffull);
+        const unsigned begin = run;
+        unsigned o[NCLS];
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) { o[k] = run; run += c[k]; }
+        *(uint4 *)(tile_off + t * NCLS) = make_uint4(o[0], o[1], o[2], o[3]);
+        *(uint4 *)(tile_off + t * NCLS + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+        *(uint4 *)(tile_cur + t * NCLS) = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4 *)(tile_cur + t * NCLS + 4) = make_uint4(0u, 0u, 0u, 0u);
+        if (run != begin) descs[ex >> 40] = TileDesc{(unsigned)t, begin, run, 0u};
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const u64 tot = front_total + own_total;
+        tile_off[ntiles * NCLS] = (unsigned)(tot & 0xffffffffffull);
+        *n_desc = (unsigned)(tot >> 40);
+        if (total_out) *total_out = (i64)(tot & 0xffffffffffull);
+    }
+}
+
+// Persistent workgroups: workgroup b rasterises the non-empty tiles b, b + G,
+// b + 2G ... (G = grid size) and fetches the next tile's descriptor and first
+// entries while the current tile is still being rasterised, so the per-tile
+// latency chain (descriptor -> entries) is off the critical path.
+// WRITE_IDMAP: store winner + 1 of every pixel of a non-empty tile to
+// idmap[v][x][y] (the caller pre-zeroes idmap).  Otherwise mark
+// seen[v][winner] = 1 (exact mode).
+constexpr int ZB_THREADS = 512;                 // 8 waves per tile: 4 workgroups = 32 waves per CU
+constexpr int ZB_QUARTERS = ZB_THREADS / 16;
+
 template <bool WRITE_IDMAP>
-__global__ __launch_bounds__(256) void tile_zbuffer_kernel(
-    const TileEntry *__restrict__ entries, const unsigned *__restrict__ tile_off,
-    i64 pair_capacity, int tiles_y, int tiles_per_view, int W, int Hc,
-    uint8_t *__restrict__ seen, i64 seen_stride, unsigned *__restrict__ idmap)
+__global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
+    const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
+    const unsigned *__restrict__ n_desc, unsigned *__restrict__ queue, i64 pair_capacity,
+    int tiles_y, int tiles_per_view, int W, int Hc, uint8_t *__restrict__ seen, i64 seen_stride,
+    unsigned *__restrict__ idmap)
 {
     __shared__ u64 zb[TILE * TILE];
-    const unsigned t = blockIdx.x;
-    const int v = t / tiles_per_view;
-    const int lt = t - v * tiles_per_view;
-    const int tx = lt / tiles_y, ty = lt - tx * tiles_y;
-    const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
-    i64 begin = tile_off[t], end = tile_off[t + 1];
+    __shared__ unsigned s_next;
+    const unsigned nd = *n_desc;
+    unsigned k = blockIdx.x;
+    if (k >= nd) return;
+    // tiles are handed out dynamically: the first two of a workgroup are
+    // blockIdx and blockIdx + G, the following ones come from a global ticket
+    // fetched one tile ahead, so that the next tile's descriptor and first
+    // entries can be prefetched while the current tile is rasterised
+    unsigned kn = k + gridDim.x;
+    const int tid = threadIdx.x;
+    const int ly = tid & 15;
+    const int slot = ly * ZB_QUARTERS + (tid >> 4);   // entry of this lane inside a group
+
+    TileDesc d = descs[k];
+    i64 begin = d.begin, end = d.end;
     if (end > pair_capacity) end = pair_capacity;
     if (begin > end) begin = end;
-    const int tid = threadIdx.x;
-
-    if (begin == end) {
-        if (WRITE_IDMAP) {
-            unsigned *im = idmap + (size_t)v * W * Hc;
-            for (int p = tid; p < TILE * TILE; p += 256) {
-                const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
-                if (gx < W && gy < Hc) im[(size_t)gx * Hc + gy] = 0u;
-            }
-        }
-        return;
-    }
-
-    const int ly = tid & 15;
-    const int slot = ly * 16 + (tid >> 4);        // entry of this lane inside a group of 256
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
     if (begin + slot < end) raw = *(const uint4 *)(entries + begin + slot);
-
-    for (int p = tid; p < TILE * TILE; p += 256) zb[p] = ZB_EMPTY;
+    for (int p = tid; p < TILE * TILE; p += ZB_THREADS) zb[p] = ZB_EMPTY;
     __syncthreads();
 
-    for (i64 base = begin; base < end; base += 256) {
-        const i64 rem = end - base;
-        // prefetch the next group while this one is rasterised
-        uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
-        if (base + 256 + slot < end) nxt = *(const uint4 *)(entries + base + 256 + slot);
-        const unsigned box = clip_box(raw, x0, y0, slot < rem);
-        const unsigned klo = raw.x, khi = raw.y;
-        const int maxj = rem >= 256 ? 16 : (int)((rem + 15) >> 4);   // lanes in use per quarter
-#define MVF_RASTER(J) if (J < maxj) raster_entry<J>(zb, klo, khi, box, ly);
-        MVF_RASTER(0) MVF_RASTER(1) MVF_RASTER(2) MVF_RASTER(3)
-        MVF_RASTER(4) MVF_RASTER(5) MVF_RASTER(6) MVF_RASTER(7)
-        MVF_RASTER(8) MVF_RASTER(9) MVF_RASTER(10) MVF_RASTER(11)
-        MVF_RASTER(12) MVF_RASTER(13) MVF_RASTER(14) MVF_RASTER(15)
+    while (true) {
+        const bool more = kn < nd;
+        unsigned ticket = 0;
+        if (more && tid == 0) ticket = atomicAdd(queue, 1u) + 2u * gridDim.x;
+        TileDesc dn = d;
+        if (more) dn = descs[kn];
+        i64 nbegin = dn.begin, nend = dn.end;
+        if (nend > pair_capacity) nend = pair_capacity;
+        if (nbegin > nend) nbegin = nend;
+        uint4 raw_n = make_uint4(0u, 0u, 0u, 0u);
+
+        const int v = d.tile / tiles_per_view;
+        const int lt = d.tile - v * tiles_per_view;
+        const int tx = lt / tiles_y, ty = lt - tx * tiles_y;
+        const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
+
+        for (i64 base = begin; base < end; base += ZB_THREADS) {
+            const i64 rem = end - base;
+            // prefetch the next group (or the next tile's first group)
+            uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
+            if (base + ZB_THREADS < end) {
+                if (base + ZB_THREADS + slot < end) nxt = *(const uint4 *)(entries + base + ZB_THREADS + slot);
+            } else if (more && nbegin + slot < nend) {
+                raw_n = *(const uint4 *)(entries + nbegin + slot);
+            }
+            const uint4 mine = stage_entry(raw, x0, y0, slot < rem);
+            const int maxj = rem >= ZB_THREADS ? 16 : (int)((rem + ZB_QUARTERS - 1) / ZB_QUARTERS);   // lanes in use per quarter
+#define MVF_RASTER(J) if (J < maxj) raster_entry<J>(zb, mine, (unsigned)ly);
+            MVF_RASTER(0) MVF_RASTER(1) MVF_RASTER(2) MVF_RASTER(3)
+            MVF_RASTER(4) MVF_RASTER(5) MVF_RASTER(6) MVF_RASTER(7)
+            MVF_RASTER(8) MVF_RASTER(9) MVF_RASTER(10) MVF_RASTER(11)
+            MVF_RASTER(12) MVF_RASTER(13) MVF_RASTER(14) MVF_RASTER(15)
 #undef MVF_RASTER
-        raw = nxt;
-    }
-    __syncthreads();
+            raw = nxt;
+        }
+        __syncthreads();
 
-    if (WRITE_IDMAP) {
-        unsigned *im = idmap + (size_t)v * W * Hc;
-        for (int p = tid; p < TILE * TILE; p += 256) {
-            const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
-            if (gx < W && gy < Hc) {
-                const u64 key = zb[p];
-                im[(size_t)gx * Hc + gy] = key == ZB_EMPTY ? 0u : (unsigned)key + 1u;
+        // read out the tile and reset it for the next one in the same sweep
+        if (WRITE_IDMAP) {
+            unsigned *im = idmap + (size_t)v * W * Hc;
+            for (int p = tid; p < TILE * TILE; p += ZB_THREADS) {
+                const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
+                const u64 kk = zb[p];
+                zb[p] = ZB_EMPTY;
+                if (gx < W && gy < Hc && kk != ZB_EMPTY) im[(size_t)gx * Hc + gy] = (unsigned)kk + 1u;
+            }
+        } else {
+            uint8_t *sv = seen + (size_t)v * seen_stride;
+            for (int p = tid; p < TILE * TILE; p += ZB_THREADS) {
+                const u64 kk = zb[p];
+                // one store per vertical run of the same winner; a neighbour that
+                // was already reset only costs a redundant store
+                const u64 up = (p & (TILE - 1)) != 0 ? zb[p - 1] : ZB_EMPTY;
+                zb[p] = ZB_EMPTY;
+                if (kk != ZB_EMPTY && !(up != ZB_EMPTY && (unsigned)up == (unsigned)kk))
+                    sv[(unsigned)kk] = 1;
             }
         }
-    } else {
-        uint8_t *sv = seen + (size_t)v * seen_stride;
-        for (int p = tid; p < TILE * TILE; p += 256) {
-            const u64 key = zb[p];
-            if (key == ZB_EMPTY) continue;
-            const unsigned w = (unsigned)key;
-            // one store per vertical run of the same winner
-            if ((p & (TILE - 1)) != 0) {
-                const u64 up = zb[p - 1];
-                if (up != ZB_EMPTY && (unsigned)up == w) continue;
-            }
-            sv[w] = 1;
-        }
+        if (!more) break;
+        if (tid == 0) s_next = ticket;
+        k = kn; d = dn; begin = nbegin; end = nend; raw = raw_n;
+        __syncthreads();
+        kn = s_next;
     }
 }
 
@@ -604,6 +712,21 @@ extern "C" int mvf_camera_projection(
     return MVF_OK;
 }
 
+// Persistent z-buffer grid: 4 workgroups of 512 threads (32 KB LDS each) per CU.
+static unsigned zb_grid(i64 tiles)
+{
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    const i64 g = (i64)cus * 4;
+    return (unsigned)(tiles < g ? tiles : g);
+}
+
 static inline void tile_grid(const mvf_vis_params &P, int &tiles_x, int &tiles_y, int &Hc)
 {
     Hc = P.H - P.crop_top - P.crop_bottom;
@@ -617,7 +740,8 @@ extern "C" size_t mvf_splat_visibility_workspace_bytes(
     const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const size_t npix = (size_t)W * H;
     size_t b = 0;
-    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;                // count, off, cur
+    b += align_up((tiles * NCLS + 4) * sizeof(unsigned)) * 3;         // count, off, cur
+    b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)(m > 0 ? m : 1));                           // seen
     b += align_up(npix * sizeof(unsigned));                           // idmap
@@ -644,9 +768,13 @@ extern "C" int mvf_splat_visibility(
     const i64 npix = (i64)P.W * Hc;
 
     Arena ar(workspace, workspace_bytes);
-    unsigned *tile_count = ar.take<unsigned>(tiles + 1);
-    unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
-    unsigned *tile_off = ar.take<unsigned>(tiles + 1);
+    // counters are [tile][class]; two extra words behind tile_count: number of
+    // non-empty tiles, z-buffer ticket counter
+    const i64 ncnt = tiles * NCLS;
+    unsigned *tile_count = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_cur = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_off = ar.take<unsigned>(ncnt + 4);
+    TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>(m);
     unsigned *idmap = ar.take<unsigned>(npix);
@@ -654,42 +782,41 @@ extern "C" int mvf_splat_visibility(
     if (!ar.ok()) { set_error("splat_visibility: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     // tile_count and tile_cur are adjacent: one memset; counters too
-    MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + 4) * sizeof(unsigned), st));
     MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
-    if (P.exact) {
-        MVF_HIP(hipMemsetAsync(seen, 0, (size_t)m, st));
-        MVF_HIP(hipMemsetAsync(idmap, 0, (size_t)npix * sizeof(unsigned), st));
-    }
+    if (P.exact) MVF_HIP(hipMemsetAsync(seen, 0, (size_t)m, st));
+    MVF_HIP(hipMemsetAsync(idmap, 0, (size_t)npix * sizeof(unsigned), st));
 
     ArraySrc src{x_proj, y_proj, dist, fx, fy, (i64)m};
     dim3 grid_m(cdiv(m, 256), 1), block(256);
-    if (tiles <= BIN_MAX_TILES)
+    if (ncnt <= BIN_MAX_COUNTERS)
         hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, true>), grid_m, block,
-                           (size_t)tiles * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
+                           (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
                            tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0);
     else
         hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, false>), grid_m, block, 0, st, src, P,
                            tiles_y, (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0,
                            (i64 *)nullptr, (int *)nullptr, 0);
-    hipLaunchKernelGGL((scan_single_block_kernel<unsigned, unsigned, i64>), dim3(1), dim3(1024), 0, st,
-                       tile_count, tiles, tile_off, (i64 *)counters + 1);
-    if (tiles <= BIN_MAX_TILES)
+    // tile_count[tiles] doubles as the number of non-empty tiles
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
+                       descs, tile_count + ncnt, (i64 *)counters + 1);
+    if (ncnt <= BIN_MAX_COUNTERS)
         hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, true>), grid_m, block,
-                           2 * (size_t)tiles * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
+                           (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
                            tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     else
         hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, false>), grid_m, block, 0, st, src, P, tiles_y,
                            (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     if (P.exact) {
-        hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
-                           tile_off, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc, seen, (i64)m,
-                           (unsigned *)nullptr);
+        hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+                           descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
+                           seen, (i64)m, (unsigned *)nullptr);
         hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
                            P.crop_top, Hc, idmap);
     } else {
-        hipLaunchKernelGGL((tile_zbuffer_kernel<true>), dim3((unsigned)tiles), block, 0, st, entries,
-                           tile_off, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
+        hipLaunchKernelGGL((tile_zbuffer_kernel<true>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+                           descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
                            (uint8_t *)nullptr, (i64)0, idmap);
     }
     IdmapPred pred{idmap};
@@ -757,7 +884,8 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
     const size_t words = (size_t)(V + 31) / 32;
     size_t b = 0;
-    b += align_up((tiles + 1) * sizeof(unsigned)) * 3;                           // count, cur, off
+    b += align_up((tiles * NCLS + 4) * sizeof(unsigned)) * 3;                    // count, cur, off
+    b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)V * (size_t)(n > 0 ? n : 1));                          // seen
     b += align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned));  // masks
@@ -795,9 +923,13 @@ extern "C" int mvf_map_images_exact(
     const int words = (V + 31) / 32;
 
     Arena ar(workspace, workspace_bytes);
-    unsigned *tile_count = ar.take<unsigned>(tiles + 1);
-    unsigned *tile_cur = ar.take<unsigned>(tiles + 1);
-    unsigned *tile_off = ar.take<unsigned>(tiles + 1);
+    // counters are [tile][class]; two extra words behind tile_count: number of
+    // non-empty tiles, z-buffer ticket counter
+    const i64 ncnt = tiles * NCLS;
+    unsigned *tile_count = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_cur = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_off = ar.take<unsigned>(ncnt + 4);
+    TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>((size_t)V * n);
     unsigned *masks = ar.take<unsigned>((size_t)words * num_points);
@@ -807,27 +939,27 @@ extern "C" int mvf_map_images_exact(
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
-    MVF_HIP(hipMemsetAsync(tile_count, 0, (char *)tile_off - (char *)tile_count, st));
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + 4) * sizeof(unsigned), st));
     prof_mark("memset", st);
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
-    const bool lds_bins = tiles_per_view <= BIN_MAX_TILES;
+    const bool lds_bins = tiles_per_view * NCLS <= BIN_MAX_COUNTERS;
     if (lds_bins)
         hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, true>), grid_nv, block,
-                           (size_t)tiles_per_view * sizeof(unsigned), st, src, P, tiles_y,
+                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, src, P, tiles_y,
                            tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters, view_seen, V);
     else
         hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, false>), grid_nv, block, 0, st, src, P,
                            tiles_y, tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters,
                            view_seen, V);
     prof_mark("bin_count", st);
-    hipLaunchKernelGGL((scan_single_block_kernel<unsigned, unsigned, i64>), dim3(1), dim3(1024), 0, st,
-                       tile_count, tiles, tile_off, (i64 *)counters + 1);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
+                       descs, tile_count + ncnt, (i64 *)counters + 1);
     prof_mark("tile_scan", st);
     if (lds_bins)
         hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, true>), grid_nv, block,
-                           2 * (size_t)tiles_per_view * sizeof(unsigned), st, src, P, tiles_y,
+                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, src, P, tiles_y,
                            tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     else
@@ -835,9 +967,9 @@ extern "C" int mvf_map_images_exact(
                            tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     prof_mark("bin_fill", st);
-    hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3((unsigned)tiles), block, 0, st, entries,
-                       tile_off, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc, seen, (i64)n,
-                       (unsigned *)nullptr);
+    hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+                       descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
+                       seen, (i64)n, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL(mi_centre_kernel, grid_nv, block, 0, st, src, P, seen, Hc, (u64 *)centre_ws, epoch);
     prof_mark("centre", st);
