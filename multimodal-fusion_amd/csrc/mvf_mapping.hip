@@ -86,17 +86,35 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
 // size keep those lanes busy for the same number of steps.  Counters are
 // therefore indexed [view][tile][class].
 constexpr int NCLS = 8;
+// Behind the counters of a call: the number of non-empty tiles, then the ticket
+// counters of the z-buffer kernel, one per 128 bytes (atomics on one address
+// serialise at the memory side, so the tickets are spread over ZB_QUEUES
+// counters).
+constexpr int ZB_QUEUES = 32;
+constexpr int ZB_QUEUE_STRIDE = 32;
+constexpr int BIN_TAIL = ZB_QUEUE_STRIDE * (ZB_QUEUES + 1);
 constexpr int BIN_MAX_COUNTERS = 12288;      // LDS histogram entries per block (48 KB)
 
-// Size class of a (splat, tile) pair: 0 = largest.
+// Raster cost of a (splat, tile) pair: atomic instructions a row of 16 lanes
+// needs for the clipped box of cw x ch pixels.  The lanes cover 2^lg >= ch rows
+// (at most 16) of 16 >> lg neighbouring columns at a time; boxes taller than
+// 16 rows take one pass per band of 16 rows.
+__device__ __forceinline__ unsigned raster_lg(unsigned ch)
+{
+    const unsigned hm = ch < 16u ? ch : 16u;
+    return hm <= 1u ? 0u : 32u - (unsigned)__clz(hm - 1u);
+}
+
+// Size class of a (splat, tile) pair: 0 = most expensive, classes a factor 2 apart.
 __device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
 {
     const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
-    const int cw = (b.xb < x0 + TILE ? b.xb : x0 + TILE) - (b.xa > x0 ? b.xa : x0);
-    const int ch = (b.yb < y0 + TILE ? b.yb : y0 + TILE) - (b.ya > y0 ? b.ya : y0);
-    const int l = 31 - __clz(cw * ch);              // area >= 1
-    const int c = l < 3 ? 0 : (l > 9 ? 7 : l - 2);
-    return (NCLS - 1) - c;
+    const unsigned cw = (b.xb < x0 + TILE ? b.xb : x0 + TILE) - (b.xa > x0 ? b.xa : x0);
+    const unsigned ch = (b.yb < y0 + TILE ? b.yb : y0 + TILE) - (b.ya > y0 ? b.ya : y0);
+    const unsigned sh = 4u - raster_lg(ch);                       // log2 of columns per step
+    const unsigned cost = ((ch + 15u) >> 4) * ((cw + (1u << sh) - 1u) >> sh);   // 1 .. 256
+    const int l = cost <= 1u ? 0 : 32 - __clz(cost - 1u);         // ceil(log2(cost)), 0 .. 8
+    return (NCLS - 1) - (l > NCLS - 1 ? NCLS - 1 : l);
 }
 
 template <class Src, bool ZERO_SEEN, bool USE_LDS>
@@ -220,31 +238,37 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 // lanes busy.
 template <int J> __device__ __forceinline__ unsigned row_bcast(unsigned v)
 {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x150 + J, 0xf, 0xf, false);
 }
 
+// Column pitch of the LDS image: 64 + 9 keys.  With 32 8-byte slots per bank
+// row, neighbouring columns start 9 slots apart, which keeps the 16 lanes of a
+// row on distinct slots for every lane shape (1x16, 2x8, 4x4, 8x2, 16x1).
+constexpr unsigned ZB_PITCH = TILE + 9;
+constexpr unsigned ZB_PITCH_BYTES = ZB_PITCH * 8;
+static_assert(TILE * ZB_PITCH_BYTES < 65536, "byte offsets of the LDS image are staged in 16 bits");
+
 template <int J>
-__device__ __forceinline__ void raster_entry(u64 *zb, const uint4 &mine, unsigned ly)
+__device__ __forceinline__ void raster_entry(char *zb, const uint4 &mine, unsigned ly)
 {
     const unsigned rx = row_bcast<J>(mine.x), ry = row_bcast<J>(mine.y);
     const unsigned rz = row_bcast<J>(mine.z), rw = row_bcast<J>(mine.w);
-    const unsigned h = rz >> 24;
-    const unsigned area = ((rz >> 8) & 0xffu) * h;              // 0 for a staged miss
     const u64 key = ((u64)ry << 32) | rx;
-    const unsigned q16 = rw & 31u, r16 = (rw >> 5) & 127u;
-    unsigned xo = (ly * (rw >> 12)) >> 16;                      // ly / h
-    unsigned yo = ly - xo * h;
-    u64 *col = zb + ((rz & 0xffu) << TILE_LOG) + ((rz >> 16) & 0xffu);
-    for (unsigned pid = ly; pid < area; pid += 16u) {
-        atomicMin(col + (xo << TILE_LOG) + yo, key);
-        xo += q16; yo += r16;
-        if (yo >= h) { yo -= h; xo += 1u; }
-    }
+    const unsigned h = rw & 0xffu;                               // 0 for a staged miss
+    const unsigned lg = (rw >> 8) & 0xffu;
+    const unsigned step = rw >> 16;                              // bytes between column groups
+    const unsigned end = rz >> 16;                               // byte offset one past the last column
+    const unsigned xo = ly >> lg, yo = ly - (xo << lg);
+    unsigned a0 = (rz & 0xffffu) + xo * ZB_PITCH_BYTES + (yo << 3);
+    for (unsigned row = yo; row < h; row += 16u, a0 += 128u)
+        for (unsigned a = a0; a < end; a += step) atomicMin((u64 *)(zb + a), key);
 }
 
-// Staged entry: key, clipped box (xa | w << 8 | ya << 16 | h << 24, w = 0 when
-// the entry is absent or misses the tile) and the constants of the sweep:
-// 16 / h, 16 % h and ceil(65536 / h).
+// Staged entry: key, then the byte offsets in the LDS image of the clipped
+// box's first pixel and of the column behind its last one (16 bits each), then
+// h | lg << 8 | step << 16 with 2^lg = rows covered by the 16 lanes and step =
+// byte distance of 16 >> lg columns.  h = 0 when the entry is absent or misses
+// the tile.
 __device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, bool valid)
 {
     int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
@@ -252,10 +276,9 @@ __device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, b
     xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
     xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
     if (!valid || xb <= xa || yb <= ya) return make_uint4(0u, 0u, 0u, 0u);
-    const unsigned w = xb - xa, h = yb - ya;
-    const unsigned q16 = 16u / h, r16 = 16u - q16 * h, rcp = (65536u + h - 1u) / h;
-    return make_uint4(raw.x, raw.y, (unsigned)xa | (w << 8) | ((unsigned)ya << 16) | (h << 24),
-                      q16 | (r16 << 5) | (rcp << 12));
+    const unsigned h = yb - ya, lg = raster_lg(h);
+    const unsigned first = (unsigned)xa * ZB_PITCH_BYTES + ((unsigned)ya << 3), end = (unsigned)xb * ZB_PITCH_BYTES;
+    return make_uint4(raw.x, raw.y, first | (end << 16), h | (lg << 8) | (((16u * ZB_PITCH_BYTES) >> lg) << 16));
 }
 
 // Scan of the [tile][class] counters, one tile per thread: exclusive offsets,
@@ -264,7 +287,7 @@ __device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, b
 // re-adds the counters of the tiles in front of it (a few hundred KB of L2
 // hits at most), so a single launch needs no inter-block ordering.  tile_cur
 // is cleared here for the fill pass.
-struct TileDesc { unsigned tile, begin, end, pad; };
+struct TileDesc { unsigned begin, end, view, origin; };   // origin = x0 | y0 << 16
 
 __device__ __forceinline__ u64 tile_weight(const unsigned *__restrict__ tile_count, i64 t)
 {
@@ -277,7 +300,7 @@ __device__ __forceinline__ u64 tile_weight(const unsigned *__restrict__ tile_cou
 __global__ __launch_bounds__(1024) void tile_scan_kernel(
     const unsigned *__restrict__ tile_count, i64 ntiles, unsigned *__restrict__ tile_off,
     unsigned *__restrict__ tile_cur, TileDesc *__restrict__ descs, unsigned *__restrict__ n_desc,
-    i64 *__restrict__ total_out)
+    i64 *__restrict__ total_out, int tiles_y, int tiles_per_view)
 {
     const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
     u64 front = 0;
@@ -302,7 +325,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
         *(uint4 *)(tile_off + t * NCLS + 4) = make_uint4(o[4], o[5], o[6], o[7]);
         *(uint4 *)(tile_cur + t * NCLS) = make_uint4(0u, 0u, 0u, 0u);
         *(uint4 *)(tile_cur + t * NCLS + 4) = make_uint4(0u, 0u, 0u, 0u);
-        if (run != begin) descs[ex >> 40] = TileDesc{(unsigned)t, begin, run, 0u};
+        if (run != begin) {
+            const unsigned v = (unsigned)t / (unsigned)tiles_per_view, lt = (unsigned)t - v * tiles_per_view;
+            const unsigned tx = lt / (unsigned)tiles_y, ty = lt - tx * tiles_y;
+            descs[ex >> 40] = TileDesc{begin, run, v, (tx << TILE_LOG) | (ty << (TILE_LOG + 16))};
+        }
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         const u64 tot = front_total + own_total;
@@ -322,6 +349,19 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
 constexpr int ZB_THREADS = 512;                 // 8 waves per tile: 4 workgroups = 32 waves per CU
 constexpr int ZB_QUARTERS = ZB_THREADS / 16;
 
+#ifdef MVF_ZB_DEBUG
+__device__ int g_zb_debug;     // bit 0: no raster, bit 1: no winner stores, bit 2: no readout
+#define ZBD(bit) (dbg_ & (bit))
+#else
+#define ZBD(bit) false
+#endif
+#ifdef MVF_ZB_TIMING
+__device__ unsigned long long g_zb_timing[8];
+#define ZBT(i) do { const long long now_ = clock64(); acc_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define ZBT(i)
+#endif
+
 template <bool WRITE_IDMAP>
 __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
@@ -329,94 +369,157 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     int tiles_y, int tiles_per_view, int W, int Hc, uint8_t *__restrict__ seen, i64 seen_stride,
     unsigned *__restrict__ idmap)
 {
-    __shared__ u64 zb[TILE * TILE];
+    __shared__ u64 zb[TILE * ZB_PITCH];
     __shared__ unsigned s_next;
     const unsigned nd = *n_desc;
-    unsigned k = blockIdx.x;
-    if (k >= nd) return;
-    // tiles are handed out dynamically: the first two of a workgroup are
-    // blockIdx and blockIdx + G, the following ones come from a global ticket
-    // fetched one tile ahead, so that the next tile's descriptor and first
-    // entries can be prefetched while the current tile is rasterised
-    unsigned kn = k + gridDim.x;
+    if (blockIdx.x >= nd) return;
+#ifdef MVF_ZB_DEBUG
+    const int dbg_ = g_zb_debug;
+#endif
+    // Tiles are handed out dynamically.  A workgroup always knows its next two
+    // tiles: the first three are blockIdx, + G and + 2G, the following ones
+    // come from one of ZB_QUEUES ticket counters (counter q hands out the
+    // tiles 3G + q, 3G + q + ZB_QUEUES, ...; a workgroup stays with counter
+    // blockIdx % ZB_QUEUES and stops when that one runs dry).  The descriptor of the tile after the next is
+    // requested while the current tile is rasterised, and so are the first
+    // entries of the next tile, so neither load is waited for.
+    unsigned k1 = blockIdx.x + gridDim.x, k2 = k1 + gridDim.x;
+    const unsigned q = blockIdx.x % ZB_QUEUES;
+    queue += q * ZB_QUEUE_STRIDE;
     const int tid = threadIdx.x;
     const int ly = tid & 15;
     const int slot = ly * ZB_QUARTERS + (tid >> 4);   // entry of this lane inside a group
 
-    TileDesc d = descs[k];
+#ifdef MVF_ZB_TIMING
+    long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
+    TileDesc d = descs[blockIdx.x];
+    TileDesc d1 = d;
+    if (k1 < nd) d1 = descs[k1];
     i64 begin = d.begin, end = d.end;
     if (end > pair_capacity) end = pair_capacity;
     if (begin > end) begin = end;
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
     if (begin + slot < end) raw = *(const uint4 *)(entries + begin + slot);
-    for (int p = tid; p < TILE * TILE; p += ZB_THREADS) zb[p] = ZB_EMPTY;
+    for (int p = tid; p < (int)(TILE * ZB_PITCH); p += ZB_THREADS) zb[p] = ZB_EMPTY;
     __syncthreads();
+    ZBT(0);
 
     while (true) {
-        const bool more = kn < nd;
-        unsigned ticket = 0;
-        if (more && tid == 0) ticket = atomicAdd(queue, 1u) + 2u * gridDim.x;
-        TileDesc dn = d;
-        if (more) dn = descs[kn];
-        i64 nbegin = dn.begin, nend = dn.end;
+        const bool more = k1 < nd;
+        i64 nbegin = d1.begin, nend = d1.end;          // requested one tile ago
         if (nend > pair_capacity) nend = pair_capacity;
         if (nbegin > nend) nbegin = nend;
+        unsigned ticket = 0;
+        TileDesc d2 = d1;
         uint4 raw_n = make_uint4(0u, 0u, 0u, 0u);
 
-        const int v = d.tile / tiles_per_view;
-        const int lt = d.tile - v * tiles_per_view;
-        const int tx = lt / tiles_y, ty = lt - tx * tiles_y;
-        const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
+        const int v = d.view;
+        const int x0 = d.origin & 0xffffu, y0 = d.origin >> 16;
 
-        for (i64 base = begin; base < end; base += ZB_THREADS) {
+        i64 base = begin;
+        do {
             const i64 rem = end - base;
-            // prefetch the next group (or the next tile's first group)
+            ZBT(1);
+            const uint4 mine = stage_entry(raw, x0, y0, slot < rem);
+            ZBT(2);
             uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
             if (base + ZB_THREADS < end) {
+                // prefetch the next group
                 if (base + ZB_THREADS + slot < end) nxt = *(const uint4 *)(entries + base + ZB_THREADS + slot);
-            } else if (more && nbegin + slot < nend) {
-                raw_n = *(const uint4 *)(entries + nbegin + slot);
+            } else {
+                // last group: request what the coming tiles need (their first
+                // entries, a ticket, a descriptor); nothing of it is looked
+                // at before the raster loop below is through
+                if (more && nbegin + slot < nend) raw_n = *(const uint4 *)(entries + nbegin + slot);
+                if (more && tid == 0) ticket = atomicAdd(queue, 1u);
+                if (k2 < nd) d2 = descs[k2];
             }
-            const uint4 mine = stage_entry(raw, x0, y0, slot < rem);
             const int maxj = rem >= ZB_THREADS ? 16 : (int)((rem + ZB_QUARTERS - 1) / ZB_QUARTERS);   // lanes in use per quarter
-#define MVF_RASTER(J) if (J < maxj) raster_entry<J>(zb, mine, (unsigned)ly);
+#define MVF_RASTER(J) if (J < maxj && !ZBD(1)) raster_entry<J>((char *)zb, mine, (unsigned)ly);
             MVF_RASTER(0) MVF_RASTER(1) MVF_RASTER(2) MVF_RASTER(3)
             MVF_RASTER(4) MVF_RASTER(5) MVF_RASTER(6) MVF_RASTER(7)
             MVF_RASTER(8) MVF_RASTER(9) MVF_RASTER(10) MVF_RASTER(11)
             MVF_RASTER(12) MVF_RASTER(13) MVF_RASTER(14) MVF_RASTER(15)
 #undef MVF_RASTER
             raw = nxt;
-        }
+            base += ZB_THREADS;
+            ZBT(3);
+        } while (base < end);
+#ifdef MVF_ZB_TIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        ZBT(4);
+#endif
         __syncthreads();
+        ZBT(5);
 
-        // read out the tile and reset it for the next one in the same sweep
-        if (WRITE_IDMAP) {
-            unsigned *im = idmap + (size_t)v * W * Hc;
-            for (int p = tid; p < TILE * TILE; p += ZB_THREADS) {
-                const int gx = x0 + (p >> TILE_LOG), gy = y0 + (p & (TILE - 1));
-                const u64 kk = zb[p];
-                zb[p] = ZB_EMPTY;
-                if (gx < W && gy < Hc && kk != ZB_EMPTY) im[(size_t)gx * Hc + gy] = (unsigned)kk + 1u;
-            }
-        } else {
-            uint8_t *sv = seen + (size_t)v * seen_stride;
-            for (int p = tid; p < TILE * TILE; p += ZB_THREADS) {
-                const u64 kk = zb[p];
-                // one store per vertical run of the same winner; a neighbour that
-                // was already reset only costs a redundant store
-                const u64 up = (p & (TILE - 1)) != 0 ? zb[p - 1] : ZB_EMPTY;
-                zb[p] = ZB_EMPTY;
-                if (kk != ZB_EMPTY && !(up != ZB_EMPTY && (unsigned)up == (unsigned)kk))
-                    sv[(unsigned)kk] = 1;
+        // read out the tile and reset it for the next one: every thread owns 8
+        // vertically adjacent pixels (one 64-byte piece of a column)
+        if (!ZBD(4)) {
+            static_assert(ZB_THREADS * 8 == TILE * TILE, "one 8-pixel piece per thread");
+            u64 *cell = zb + (tid >> 3) * ZB_PITCH + (tid & 7) * 8;
+            unsigned id[8], left[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) id[k] = (unsigned)cell[k];      // empty cells read 0xffffffff
+            // Winner of the same row in the column to the left.  That column
+            // belongs to lane - 8 of the same wave, whose reset below comes
+            // after this read in program order; the first 8 lanes of a wave
+            // would race with another wave and go without.
+            const bool has_left = (tid & 63) >= 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) left[k] = has_left ? (unsigned)cell[k - (int)ZB_PITCH] : 0xffffffffu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cell[k] = ZB_EMPTY;
+            if (WRITE_IDMAP) {
+                const int gx = x0 + (tid >> 3), gy = y0 + (tid & 7) * 8;
+                if (gx < W) {
+                    unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
+                }
+            } else {
+                uint8_t *sv = seen + (size_t)v * seen_stride;
+                // a winner is marked where neither the pixel above (inside the
+                // piece) nor the pixel to the left shows it: its top-left
+                // visible pixel always qualifies
+                unsigned prev = 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2)) sv[id[k]] = 1;
+                    prev = id[k];
+                }
             }
         }
+        ZBT(6);
         if (!more) break;
-        if (tid == 0) s_next = ticket;
-        k = kn; d = dn; begin = nbegin; end = nend; raw = raw_n;
+        if (tid == 0) s_next = 3u * gridDim.x + q + ticket * ZB_QUEUES;
+        k1 = k2; d = d1; d1 = d2; begin = nbegin; end = nend; raw = raw_n;
         __syncthreads();
-        kn = s_next;
+        k2 = s_next;
+        ZBT(7);
     }
+#ifdef MVF_ZB_TIMING
+    if ((tid & 63) == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_zb_timing[i], (unsigned long long)acc_[i]);
+#endif
 }
+
+#ifdef MVF_ZB_DEBUG
+extern "C" int mvf_debug_zb_switch(int mask)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_zb_debug), &mask, sizeof(mask)) != hipSuccess;
+}
+#endif
+
+#ifdef MVF_ZB_TIMING
+extern "C" int mvf_debug_zb_timing(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zb_timing), sizeof(g_zb_timing)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_zb_timing), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------- //
 // exact mode for the single-view API: stamp splat centres of seen points      //
@@ -740,7 +843,7 @@ extern "C" size_t mvf_splat_visibility_workspace_bytes(
     const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     const size_t npix = (size_t)W * H;
     size_t b = 0;
-    b += align_up((tiles * NCLS + 4) * sizeof(unsigned)) * 3;         // count, off, cur
+    b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;         // count, off, cur
     b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)(m > 0 ? m : 1));                           // seen
@@ -771,9 +874,9 @@ extern "C" int mvf_splat_visibility(
     // counters are [tile][class]; two extra words behind tile_count: number of
     // non-empty tiles, z-buffer ticket counter
     const i64 ncnt = tiles * NCLS;
-    unsigned *tile_count = ar.take<unsigned>(ncnt + 4);
-    unsigned *tile_cur = ar.take<unsigned>(ncnt + 4);
-    unsigned *tile_off = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_count = ar.take<unsigned>(ncnt + BIN_TAIL);
+    unsigned *tile_cur = ar.take<unsigned>(ncnt + BIN_TAIL);
+    unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
     TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>(m);
@@ -782,7 +885,7 @@ extern "C" int mvf_splat_visibility(
     if (!ar.ok()) { set_error("splat_visibility: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     // tile_count and tile_cur are adjacent: one memset; counters too
-    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + 4) * sizeof(unsigned), st));
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
     MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
     if (P.exact) MVF_HIP(hipMemsetAsync(seen, 0, (size_t)m, st));
     MVF_HIP(hipMemsetAsync(idmap, 0, (size_t)npix * sizeof(unsigned), st));
@@ -799,7 +902,7 @@ extern "C" int mvf_splat_visibility(
                            (i64 *)nullptr, (int *)nullptr, 0);
     // tile_count[tiles] doubles as the number of non-empty tiles
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
-                       descs, tile_count + ncnt, (i64 *)counters + 1);
+                       descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, (int)tiles);
     if (ncnt <= BIN_MAX_COUNTERS)
         hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, true>), grid_m, block,
                            (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
@@ -810,13 +913,13 @@ extern "C" int mvf_splat_visibility(
                            (i64 *)counters + 2);
     if (P.exact) {
         hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
-                           descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
+                           descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
                            seen, (i64)m, (unsigned *)nullptr);
         hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
                            P.crop_top, Hc, idmap);
     } else {
         hipLaunchKernelGGL((tile_zbuffer_kernel<true>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
-                           descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
+                           descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
                            (uint8_t *)nullptr, (i64)0, idmap);
     }
     IdmapPred pred{idmap};
@@ -884,7 +987,7 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
     const size_t words = (size_t)(V + 31) / 32;
     size_t b = 0;
-    b += align_up((tiles * NCLS + 4) * sizeof(unsigned)) * 3;                    // count, cur, off
+    b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;                    // count, cur, off
     b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
     b += align_up((size_t)V * (size_t)(n > 0 ? n : 1));                          // seen
@@ -926,9 +1029,9 @@ extern "C" int mvf_map_images_exact(
     // counters are [tile][class]; two extra words behind tile_count: number of
     // non-empty tiles, z-buffer ticket counter
     const i64 ncnt = tiles * NCLS;
-    unsigned *tile_count = ar.take<unsigned>(ncnt + 4);
-    unsigned *tile_cur = ar.take<unsigned>(ncnt + 4);
-    unsigned *tile_off = ar.take<unsigned>(ncnt + 4);
+    unsigned *tile_count = ar.take<unsigned>(ncnt + BIN_TAIL);
+    unsigned *tile_cur = ar.take<unsigned>(ncnt + BIN_TAIL);
+    unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
     TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
     uint8_t *seen = ar.take<uint8_t>((size_t)V * n);
@@ -939,7 +1042,7 @@ extern "C" int mvf_map_images_exact(
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
-    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + 4) * sizeof(unsigned), st));
+    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
     prof_mark("memset", st);
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
@@ -955,7 +1058,7 @@ extern "C" int mvf_map_images_exact(
                            view_seen, V);
     prof_mark("bin_count", st);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
-                       descs, tile_count + ncnt, (i64 *)counters + 1);
+                       descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, tiles_per_view);
     prof_mark("tile_scan", st);
     if (lds_bins)
         hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, true>), grid_nv, block,
@@ -968,7 +1071,7 @@ extern "C" int mvf_map_images_exact(
                            (i64 *)counters + 2);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
-                       descs, tile_count + ncnt, tile_count + ncnt + 1, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
+                       descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
                        seen, (i64)n, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL(mi_centre_kernel, grid_nv, block, 0, st, src, P, seen, Hc, (u64 *)centre_ws, epoch);
