@@ -117,11 +117,34 @@ __device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
     return (NCLS - 1) - (l > NCLS - 1 ? NCLS - 1 : l);
 }
 
+// Range of tile indices [lo, hi) touched by the boxes of a block (hi <= lo when
+// no thread has one).  The points of a block are neighbours in space, so the
+// range is a small part of the view's tiles and the LDS histogram only needs
+// clearing and flushing there.
+__device__ __forceinline__ void block_tile_range(bool have, int t_first, int t_last, int &lo, int &hi)
+{
+    __shared__ int s_range[2];
+    if (threadIdx.x == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
+    int mn = have ? t_first : 0x7fffffff, mx = have ? t_last : -1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && mx >= 0) { atomicMin(&s_range[0], mn); atomicMax(&s_range[1], mx); }
+    __syncthreads();
+    lo = s_range[0];
+    hi = s_range[1] + 1;
+}
+
 template <class Src, bool ZERO_SEEN, bool USE_LDS>
 __global__ __launch_bounds__(256) void bin_count_kernel(
     Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
     unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride,
-    i64 *__restrict__ zero_counters, int *__restrict__ zero_view_seen, int V)
+    i64 *__restrict__ zero_counters, int *__restrict__ zero_view_seen, int V,
+    TileEntry *__restrict__ staged, unsigned *__restrict__ staged_count)
 {
     extern __shared__ unsigned hist[];
     const int tid = threadIdx.x;
@@ -133,7 +156,11 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
         if (zero_view_seen) for (int k = tid; k < V; k += 256) zero_view_seen[k] = 0;
     }
     const bool live = i < src.count();
-    if (ZERO_SEEN && live) seen[(size_t)v * seen_stride + i] = 0;
+    if (ZERO_SEEN && live && v == 0) {
+        // flags of a point over all views: seen_stride bytes, a multiple of 16
+        uint4 *row = (uint4 *)(seen + (size_t)i * seen_stride);
+        for (int k = 0; k < (int)(seen_stride >> 4); ++k) row[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     double x, y; float d = 0.f, fx, fy;
     const bool have = live && src.get(i, v, P, x, y, d, fx, fy);
     BBox b{0, 0, 0, 0};
@@ -142,16 +169,32 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     const int ncnt = tiles_per_view * NCLS;
     unsigned *tc = tile_count + (size_t)v * ncnt;
+    {
+        // the boxes are kept for the fill pass, packed per block
+        unsigned total;
+        const unsigned rank = block_rank_flag(have, total);
+        const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
+        if (tid == 0) staged_count[blk] = total;
+        if (have) {
+            TileEntry e;
+            e.key = depth_key(d, (unsigned)i);
+            e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
+            staged[blk * 256 + rank] = e;
+        }
+    }
     if (USE_LDS) {
-        if (!__syncthreads_or(have)) return;
-        for (int t = tid; t < ncnt; t += 256) hist[t] = 0;
+        int lo, hi;
+        block_tile_range(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, lo, hi);
+        if (hi <= lo) return;
+        lo *= NCLS; hi *= NCLS;
+        for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
                 for (int ty = ty0; ty <= ty1; ++ty)
                     atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
         __syncthreads();
-        for (int t = tid; t < ncnt; t += 256) {
+        for (int t = lo + tid; t < hi; t += 256) {
             const unsigned c = hist[t];
             if (c) atomicAdd(&tc[t], c);
         }
@@ -162,30 +205,34 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     }
 }
 
-template <class Src, bool USE_LDS>
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void bin_fill_kernel(
-    Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
+    const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
+    int tiles_y, int tiles_per_view,
     const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
     TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
 {
     extern __shared__ unsigned hist[];   // per (tile, class): count, then absolute write cursor
     const int tid = threadIdx.x;
-    const i64 i = (i64)blockIdx.x * 256 + tid;
     const int v = blockIdx.y;
-    double x, y; float d = 0.f, fx, fy;
-    const bool have = i < src.count() && src.get(i, v, P, x, y, d, fx, fy);
-    BBox b{0, 0, 0, 0};
-    if (have) b = splat_bbox(x, y, d, fx, fy, P);
+    const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
+    const unsigned n = staged_count[blk];
+    if (n == 0) return;
+    const bool have = (unsigned)tid < n;
+    TileEntry e;
+    e.key = 0; e.xa = e.xb = e.ya = e.yb = 0;
+    if (have) e = staged[blk * 256 + tid];
+    const BBox b{(int)e.xa, (int)e.xb, (int)e.ya, (int)e.yb};
     const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
-    TileEntry e;
-    e.key = depth_key(d, (unsigned)i);
-    e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
     const int ncnt = tiles_per_view * NCLS;
     const size_t cbase = (size_t)v * ncnt;
     if (USE_LDS) {
-        if (!__syncthreads_or(have)) return;
-        for (int t = tid; t < ncnt; t += 256) hist[t] = 0;
+        int lo, hi;
+        block_tile_range(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, lo, hi);
+        if (hi <= lo) return;
+        lo *= NCLS; hi *= NCLS;
+        for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
@@ -193,7 +240,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
                     atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
         __syncthreads();
         // one global reservation per touched counter; hist becomes the write cursor
-        for (int t = tid; t < ncnt; t += 256) {
+        for (int t = lo + tid; t < hi; t += 256) {
             const unsigned c = hist[t];
             if (c) hist[t] = tile_off[cbase + t] + atomicAdd(&tile_cur[cbase + t], c);
         }
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
 // latency chain (descriptor -> entries) is off the critical path.
 // WRITE_IDMAP: store winner + 1 of every pixel of a non-empty tile to
 // idmap[v][x][y] (the caller pre-zeroes idmap).  Otherwise mark
-// seen[v][winner] = 1 (exact mode).
+// seen[winner][v] = 1 (exact mode; seen_stride bytes per point).
 constexpr int ZB_THREADS = 512;                 // 8 waves per tile: 4 workgroups = 32 waves per CU
 constexpr int ZB_QUARTERS = ZB_THREADS / 16;
 
@@ -479,14 +526,14 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
                         if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
                 }
             } else {
-                uint8_t *sv = seen + (size_t)v * seen_stride;
+                uint8_t *sv = seen + v;
                 // a winner is marked where neither the pixel above (inside the
                 // piece) nor the pixel to the left shows it: its top-left
                 // visible pixel always qualifies
                 unsigned prev = 0xffffffffu;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2)) sv[id[k]] = 1;
+                    if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2)) sv[(size_t)id[k] * seen_stride] = 1;
                     prev = id[k];
                 }
             }
@@ -607,36 +654,58 @@ __global__ __launch_bounds__(256) void features_kernel(
 // ------------------------------------------------------------------------- //
 // fused MapImages (exact): centre conflicts + CSR assembly                    //
 // ------------------------------------------------------------------------- //
-// After the tile pass seen[v][i] tells which points own a z-buffer pixel.
+// After the tile pass seen[i][v] (one byte per view, rows of seen_stride bytes,
+// a multiple of 16) tells which points own a z-buffer pixel.
 // centre_ws[v][x][y] is a persistent 64-bit map: atomicMax of
 // (epoch << 32 | i + 1) keeps, per centre pixel, the highest local index of
 // this call -- the reference's ascending overwrite (visibility.py:1183-1187);
 // entries of earlier calls carry a smaller epoch and always lose.
+
+// Bit mask of the views [16 * chunk, 16 * chunk + 16) that see point i.
+__device__ __forceinline__ unsigned seen_chunk(const uint8_t *seen, i64 seen_stride, i64 i, int chunk)
+{
+    const uint4 f = *(const uint4 *)(seen + (size_t)i * seen_stride + 16 * chunk);
+    const unsigned w[4] = {f.x, f.y, f.z, f.w};
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // flags are 0 or 1: gather the low bit of each byte
+        const unsigned t = w[k] & 0x01010101u;
+        m |= (((t * 0x01020408u) >> 24) & 0xfu) << (4 * k);
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void mi_centre_kernel(
-    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
+    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int V, int Hc,
     u64 *__restrict__ centre_ws, unsigned epoch)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    const int v = blockIdx.y;
-    if (i >= src.n || !seen[(size_t)v * src.n + i]) return;
-    double x, y; float d, fx, fy;
-    if (!src.get(i, v, P, x, y, d, fx, fy)) return;
-    const int cx = (int)x, cy = (int)y - P.crop_top;
-    atomicMax(&centre_ws[((size_t)v * P.W + cx) * Hc + cy], ((u64)epoch << 32) | (u64)((unsigned)i + 1u));
+    if (i >= src.n) return;
+    for (int chunk = 0; chunk * 16 < V; ++chunk) {
+        unsigned m = seen_chunk(seen, seen_stride, i, chunk);
+        while (m) {
+            const int v = 16 * chunk + __ffs(m) - 1;
+            m &= m - 1;
+            double x, y; float d, fx, fy;
+            if (!src.get(i, v, P, x, y, d, fx, fy)) continue;
+            const int cx = (int)x, cy = (int)y - P.crop_top;
+            atomicMax(&centre_ws[((size_t)v * P.W + cx) * Hc + cy], ((u64)epoch << 32) | (u64)((unsigned)i + 1u));
+        }
+    }
 }
 
 struct PixelXform { int up, down, crop_w, crop_h; };
 
-// Shared by the count and the fill pass: does point position i keep a mapping
-// in view v, and at which (converted) pixel?  0 = not mapped, 1 = mapped by the
-// visibility model but outside the crop (the view still counts as seen,
-// image.py:289-290,350), 2 = kept.
+// Shared by the count and the fill pass: does the seen point position i keep
+// its mapping in view v, and at which (converted) pixel?  0 = not mapped, 1 =
+// mapped by the visibility model but outside the crop (the view still counts
+// as seen, image.py:289-290,350), 2 = kept.
 __device__ __forceinline__ int mi_survives(
-    const CloudSrc &src, const mvf_vis_params &P, const uint8_t *seen, int Hc,
+    const CloudSrc &src, const mvf_vis_params &P, int Hc,
     const u64 *centre_ws, unsigned epoch, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
-    if (!seen[(size_t)v * src.n + i]) return 0;
     double x, y; float fx, fy;
     if (!src.get(i, v, P, x, y, dist, fx, fy)) return 0;
     const int cx = (int)x, cy = (int)y;
@@ -664,12 +733,12 @@ __device__ __forceinline__ void mi_pixel(
     y_proj = y;
 }
 
-// Pass 1 of the CSR assembly: one thread per output point id.  Gathers the
-// seen flags of its point over all views (independent loads first), resolves
-// centre-pixel conflicts and the crop, stores the kept-view bit masks
-// masks[word][q] and the block's mapping count.
+// Pass 1 of the CSR assembly: one thread per output point id.  Reads the seen
+// flags of its point (16 views per load), resolves centre-pixel conflicts and
+// the crop, stores the kept-view bit masks masks[word][q] and the block's
+// mapping count.
 __global__ __launch_bounds__(256) void mi_point_mask_kernel(
-    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, int Hc,
+    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int Hc,
     const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
@@ -681,10 +750,8 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     for (int wd = 0; wd < words; ++wd) {
         unsigned sm = 0;
         if (i >= 0) {
-            const int vend = V - (wd << 5) < 32 ? V - (wd << 5) : 32;
-            const uint8_t *sp = seen + (size_t)(wd << 5) * src.n + i;
-#pragma unroll 8
-            for (int bit = 0; bit < vend; ++bit) sm |= (sp[(size_t)bit * src.n] ? 1u : 0u) << bit;
+            sm = seen_chunk(seen, seen_stride, i, 2 * wd);
+            if (32 * wd + 16 < V) sm |= seen_chunk(seen, seen_stride, i, 2 * wd + 1) << 16;
         }
         unsigned kept = 0;
         while (sm) {
@@ -692,7 +759,7 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
             sm &= sm - 1;
             const int v = (wd << 5) + bit;
             int px, py; float d; double yp;
-            const int s = mi_survives(src, P, seen, Hc, centre_ws, epoch, X, i, v, px, py, d, yp);
+            const int s = mi_survives(src, P, Hc, centre_ws, epoch, X, i, v, px, py, d, yp);
             if (s) view_seen[v] = 1;
             if (s == 2) kept |= 1u << bit;
         }
@@ -704,47 +771,40 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-// Pass 2 (one block): exclusive scan of the block counts, grand total, and
-// the rank of each seen view among the seen views (lexunique + bucketize,
-// image.py:392-394).
-__global__ __launch_bounds__(1024) void mi_spine_kernel(
-    const unsigned *__restrict__ block_sums, i64 nb, i64 *__restrict__ block_off,
-    i64 *__restrict__ pointers_end, i64 *__restrict__ counters,
-    const int *__restrict__ view_seen, int V, int *__restrict__ view_rank)
-{
-    const i64 per = (nb + 1023) / 1024;
-    const i64 lo = (i64)threadIdx.x * per;
-    const i64 hi = lo + per < nb ? lo + per : nb;
-    i64 s = 0;
-    for (i64 k = lo; k < hi; ++k) s += block_sums[k];
-    i64 total;
-    i64 run = block_exclusive_scan<i64, 16>(s, total);
-    for (i64 k = lo; k < hi; ++k) { block_off[k] = run; run += block_sums[k]; }
-    if (threadIdx.x == 0) {
-        *pointers_end = total;
-        counters[0] = total;
-        int r = 0;
-        for (int v = 0; v < V; ++v) { view_rank[v] = r; r += view_seen[v] ? 1 : 0; }
-        counters[3] = r;
-    }
-}
-
-// Pass 3: pointers + images / pixels / features of every kept mapping, views
-// ascending inside a point.
+// Pass 2: pointers + images / pixels / features of every kept mapping, views
+// ascending inside a point.  Every block adds up the counts of the blocks in
+// front of it itself, and ranks the seen views among the seen views (lexunique
+// + bucketize, image.py:392-394) in LDS; the last block also stores the totals.
 __global__ __launch_bounds__(256) void mi_fill_kernel(
     CloudSrc src, mvf_vis_params P, PixelXform X, int V, const i64 *__restrict__ inv_ids,
-    i64 num_points, const unsigned *__restrict__ masks, const i64 *__restrict__ block_off,
-    const int *__restrict__ view_rank, FeatArgs A, i64 out_capacity,
+    i64 num_points, const unsigned *__restrict__ masks, const unsigned *__restrict__ block_sums,
+    const int *__restrict__ view_seen, FeatArgs A, i64 out_capacity,
     i64 *__restrict__ pointers, i64 *__restrict__ images, int16_t *__restrict__ pixels,
-    float *__restrict__ features, i64 *__restrict__ overflow)
+    float *__restrict__ features, i64 *__restrict__ counters)
 {
+    extern __shared__ int view_rank[];                   // V + 1 ranks
+    for (int v = threadIdx.x; v <= V; v += 256) {
+        int r = 0;
+        for (int u = 0; u < v; ++u) r += view_seen[u] ? 1 : 0;
+        view_rank[v] = r;
+    }
+    i64 front = 0;
+    for (unsigned k = threadIdx.x; k < blockIdx.x; k += 256) front += block_sums[k];
+    i64 front_total;
+    block_exclusive_scan<i64>(front, front_total);       // also orders view_rank for the block
+
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     const int words = (V + 31) >> 5;
     unsigned c = 0;
     if (q < num_points)
         for (int wd = 0; wd < words; ++wd) c += __popc(masks[(size_t)wd * num_points + q]);
     unsigned total;
-    i64 k = block_off[blockIdx.x] + block_exclusive_scan<unsigned>(c, total);
+    i64 k = front_total + block_exclusive_scan<unsigned>(c, total);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        pointers[num_points] = front_total + total;
+        counters[0] = front_total + total;
+        counters[3] = view_rank[V];
+    }
     if (q >= num_points) return;
     pointers[q] = k;
     if (c == 0) return;
@@ -763,7 +823,7 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
                 write_features(features + (size_t)k * A.F, A, i, px3, py3, pz3,
                                src.views[v].img_xyz, d, yp);
             } else {
-                *overflow = 1;
+                counters[2] = 1;
             }
             ++k;
         }
@@ -830,6 +890,17 @@ static unsigned zb_grid(i64 tiles)
     return (unsigned)(tiles < g ? tiles : g);
 }
 
+// Boxes staged by the count pass for the fill pass: 256 slots and one count per
+// block of 256 points and view.
+static inline size_t staged_bytes(i64 n, int V)
+{
+    const size_t blocks = (size_t)V * cdiv(n > 0 ? n : 1, 256);
+    return align_up(blocks * 256 * sizeof(TileEntry)) + align_up(blocks * sizeof(unsigned));
+}
+
+// Bytes of one point's row of per-view flags.
+static inline i64 seen_row_bytes(int V) { return ((i64)V + 15) / 16 * 16; }
+
 static inline void tile_grid(const mvf_vis_params &P, int &tiles_x, int &tiles_y, int &Hc)
 {
     Hc = P.H - P.crop_top - P.crop_bottom;
@@ -846,6 +917,7 @@ extern "C" size_t mvf_splat_visibility_workspace_bytes(
     b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;         // count, off, cur
     b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
+    b += staged_bytes(m, 1);
     b += align_up((size_t)(m > 0 ? m : 1));                           // seen
     b += align_up(npix * sizeof(unsigned));                           // idmap
     b += align_up(compact_workspace_elems(npix) * sizeof(unsigned));
@@ -879,6 +951,8 @@ extern "C" int mvf_splat_visibility(
     unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
     TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
+    TileEntry *staged = ar.take<TileEntry>((size_t)cdiv(m, 256) * 256);
+    unsigned *staged_count = ar.take<unsigned>(cdiv(m, 256));
     uint8_t *seen = ar.take<uint8_t>(m);
     unsigned *idmap = ar.take<unsigned>(npix);
     unsigned *cblocks = ar.take<unsigned>(compact_workspace_elems(npix));
@@ -895,26 +969,27 @@ extern "C" int mvf_splat_visibility(
     if (ncnt <= BIN_MAX_COUNTERS)
         hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, true>), grid_m, block,
                            (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
-                           tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0);
+                           tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0,
+                           staged, staged_count);
     else
         hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, false>), grid_m, block, 0, st, src, P,
                            tiles_y, (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0,
-                           (i64 *)nullptr, (int *)nullptr, 0);
+                           (i64 *)nullptr, (int *)nullptr, 0, staged, staged_count);
     // tile_count[tiles] doubles as the number of non-empty tiles
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, (int)tiles);
     if (ncnt <= BIN_MAX_COUNTERS)
-        hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, true>), grid_m, block,
-                           (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
+        hipLaunchKernelGGL((bin_fill_kernel<true>), grid_m, block,
+                           (size_t)ncnt * sizeof(unsigned), st, staged, staged_count, tiles_y, (int)tiles,
                            tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     else
-        hipLaunchKernelGGL((bin_fill_kernel<ArraySrc, false>), grid_m, block, 0, st, src, P, tiles_y,
+        hipLaunchKernelGGL((bin_fill_kernel<false>), grid_m, block, 0, st, staged, staged_count, tiles_y,
                            (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     if (P.exact) {
         hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
-                           seen, (i64)m, (unsigned *)nullptr);
+                           seen, (i64)1, (unsigned *)nullptr);
         hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
                            P.crop_top, Hc, idmap);
     } else {
@@ -990,11 +1065,10 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;                    // count, cur, off
     b += align_up((tiles + 1) * sizeof(TileDesc));
     b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
-    b += align_up((size_t)V * (size_t)(n > 0 ? n : 1));                          // seen
+    b += staged_bytes(n, V);
+    b += align_up((size_t)seen_row_bytes(V) * (size_t)(n > 0 ? n : 1));         // seen
     b += align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned));  // masks
     b += align_up(nb * sizeof(unsigned));                                        // block sums
-    b += align_up(nb * sizeof(i64));                                             // block offsets
-    b += align_up((size_t)V * sizeof(int));                                      // view_rank
     return b;
 }
 
@@ -1034,11 +1108,12 @@ extern "C" int mvf_map_images_exact(
     unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
     TileDesc *descs = ar.take<TileDesc>(tiles + 1);
     TileEntry *entries = ar.take<TileEntry>(pair_capacity);
-    uint8_t *seen = ar.take<uint8_t>((size_t)V * n);
+    TileEntry *staged = ar.take<TileEntry>((size_t)V * cdiv(n, 256) * 256);
+    unsigned *staged_count = ar.take<unsigned>((size_t)V * cdiv(n, 256));
+    const i64 seen_stride = seen_row_bytes(V);
+    uint8_t *seen = ar.take<uint8_t>((size_t)seen_stride * n);
     unsigned *masks = ar.take<unsigned>((size_t)words * num_points);
     unsigned *block_sums = ar.take<unsigned>(nb);
-    i64 *block_off = ar.take<i64>(nb);
-    int *view_rank = ar.take<int>(V);
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
@@ -1051,46 +1126,45 @@ extern "C" int mvf_map_images_exact(
     if (lds_bins)
         hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, true>), grid_nv, block,
                            (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, src, P, tiles_y,
-                           tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters, view_seen, V);
+                           tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V,
+                           staged, staged_count);
     else
         hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, false>), grid_nv, block, 0, st, src, P,
-                           tiles_y, tiles_per_view, tile_count, seen, (i64)n, (i64 *)counters,
-                           view_seen, V);
+                           tiles_y, tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters,
+                           view_seen, V, staged, staged_count);
     prof_mark("bin_count", st);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, tiles_per_view);
     prof_mark("tile_scan", st);
     if (lds_bins)
-        hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, true>), grid_nv, block,
-                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, src, P, tiles_y,
-                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
+        hipLaunchKernelGGL((bin_fill_kernel<true>), grid_nv, block,
+                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, staged, staged_count,
+                           tiles_y, tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     else
-        hipLaunchKernelGGL((bin_fill_kernel<CloudSrc, false>), grid_nv, block, 0, st, src, P, tiles_y,
-                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
+        hipLaunchKernelGGL((bin_fill_kernel<false>), grid_nv, block, 0, st, staged, staged_count,
+                           tiles_y, tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
                            (i64 *)counters + 2);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
-                       seen, (i64)n, (unsigned *)nullptr);
+                       seen, seen_stride, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
-    hipLaunchKernelGGL(mi_centre_kernel, grid_nv, block, 0, st, src, P, seen, Hc, (u64 *)centre_ws, epoch);
+    hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, 0, st, src, P, seen, seen_stride, V, Hc,
+                       (u64 *)centre_ws, epoch);
     prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
-    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, 0, st, src, P, seen, Hc,
+    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, 0, st, src, P, seen, seen_stride, Hc,
                        (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_spine_kernel, dim3(1), dim3(1024), 0, st, block_sums, nb, block_off,
-                       (i64 *)pointers + num_points, (i64 *)counters, view_seen, V, view_rank);
-    prof_mark("spine", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, 0, st, src, P, X, V, (const i64 *)inv_ids,
-                       (i64)num_points, masks, block_off, view_rank,
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
+                       (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
-                       (i64 *)counters + 2);
+                       (i64 *)counters);
     prof_mark("csr_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;

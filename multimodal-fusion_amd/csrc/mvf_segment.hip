@@ -1,13 +1,15 @@
 // CSR segment kernels: the HIP replacement of torch_scatter.segment_csr and of
 // the gather / softmax helpers of modules/multimodal/pooling.py.
 //
-// Layout: src is [rows][C] float32 row-major, ptr is int64 [nseg+1].  A group
-// of LPR lanes (a power of two <= 64, chosen on the host so that one group
-// covers one row with VEC floats per lane) owns one segment and folds its rows
-// in order: sums are therefore identical from run to run and identical to a
-// sequential CPU fold.  Consecutive groups own consecutive segments, so a
-// wavefront reads a contiguous span of rows; HBM-bound: rows*C*4 bytes read
-// once, nseg*C*4 bytes written once.
+// Layout: src is [rows][C] float32 row-major, ptr is int64 [nseg+1].  The
+// output is walked as a flat array of nseg * (C / VEC) vectors: a thread owns
+// one (segment, column) pair at a time and folds the segment's rows in order,
+// so sums are identical from run to run and identical to a sequential CPU
+// fold.  Consecutive threads own consecutive output vectors (and, for the
+// short segments of the view pools, consecutive input vectors); every thread
+// keeps four independent pairs in flight because segments are short and the
+// chain ptr -> row -> store is latency-bound otherwise.  HBM-bound: rows*C*4
+// bytes read once, nseg*C*4 bytes written once.
 #include "mvf_common.h"
 
 namespace mvf {
@@ -37,39 +39,57 @@ __device__ __forceinline__ void scale_v(float4 &a, float c)
 __device__ __forceinline__ void zero_v(float &a) { a = 0.f; }
 __device__ __forceinline__ void zero_v(float4 &a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
 
+constexpr int SEG_ILP = 4;
+
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void segment_csr_kernel(
     const float *__restrict__ src, int C, const i64 *__restrict__ ptr, i64 nseg,
-    int lpr_log, float *__restrict__ out)
+    float *__restrict__ out)
 {
     typedef typename Vec<VEC>::T V;
-    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 seg = gtid >> lpr_log;
-    if (seg >= nseg) return;
-    const int lig = (int)(gtid & ((1 << lpr_log) - 1));
-    const i64 a = ptr[seg], b = ptr[seg + 1];
-    const int cv = C / VEC;              // row length in vectors
+    const unsigned cv = (unsigned)(C / VEC);             // row length in vectors
+    const i64 total = nseg * cv;
     const V *s = (const V *)src;
     V *o = (V *)out;
-    for (int c = lig; c < cv; c += (1 << lpr_log)) {
-        V acc;
-        if (b > a) {
-            const V *p = s + (size_t)a * cv + c;
-            acc = p[0];
-            i64 r = a + 1;
-            // 4 independent loads in flight, folded in row order
-            for (; r + 4 <= b; r += 4) {
-                const V *q = s + (size_t)r * cv + c;
-                const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
-                fold_v<MODE>(acc, x0); fold_v<MODE>(acc, x1);
-                fold_v<MODE>(acc, x2); fold_v<MODE>(acc, x3);
-            }
-            for (; r < b; ++r) fold_v<MODE>(acc, s[(size_t)r * cv + c]);
-            if (MODE == MVF_REDUCE_MEAN) scale_v(acc, (float)(b - a));
-        } else {
-            zero_v(acc);
+    const i64 e0 = (i64)blockIdx.x * (256 * SEG_ILP) + threadIdx.x;
+    // one 64-bit division per block, 32-bit ones per pair
+    const i64 seg0 = ((i64)blockIdx.x * (256 * SEG_ILP)) / cv;
+    const unsigned rem0 = (unsigned)((i64)blockIdx.x * (256 * SEG_ILP) - seg0 * cv) + threadIdx.x;
+    i64 a[SEG_ILP], b[SEG_ILP];
+    unsigned c[SEG_ILP];
+    V acc[SEG_ILP];
+#pragma unroll
+    for (int k = 0; k < SEG_ILP; ++k) {
+        const i64 e = e0 + k * 256;
+        a[k] = b[k] = 0;
+        c[k] = 0;
+        if (e < total) {
+            const unsigned off = rem0 + k * 256, ds = off / cv;
+            const i64 seg = seg0 + ds;
+            c[k] = off - ds * cv;
+            a[k] = ptr[seg];
+            b[k] = ptr[seg + 1];
         }
-        o[(size_t)seg * cv + c] = acc;
+    }
+    // first rows of all pairs together, then the remaining rows pair by pair
+#pragma unroll
+    for (int k = 0; k < SEG_ILP; ++k) {
+        zero_v(acc[k]);
+        if (b[k] > a[k]) acc[k] = s[(size_t)a[k] * cv + c[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < SEG_ILP; ++k) {
+        i64 r = a[k] + 1;
+        for (; r + 4 <= b[k]; r += 4) {
+            const V *q = s + (size_t)r * cv + c[k];
+            const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
+            fold_v<MODE>(acc[k], x0); fold_v<MODE>(acc[k], x1);
+            fold_v<MODE>(acc[k], x2); fold_v<MODE>(acc[k], x3);
+        }
+        for (; r < b[k]; ++r) fold_v<MODE>(acc[k], s[(size_t)r * cv + c[k]]);
+        if (MODE == MVF_REDUCE_MEAN && b[k] > a[k]) scale_v(acc[k], (float)(b[k] - a[k]));
+        const i64 e = e0 + k * 256;
+        if (e < total) o[e] = acc[k];
     }
 }
 
@@ -143,11 +163,10 @@ extern "C" int mvf_segment_csr(
     MVF_REQUIRE(ptr && out && (src || rows == 0), "segment_csr: null pointer");
     int vec, lpr_log;
     pick_layout(src, out, C, vec, lpr_log);
-    const i64 threads = nseg << lpr_log;
-    dim3 grid(cdiv(threads, 256)), block(256);
+    dim3 grid(cdiv(nseg * (C / vec), 256 * SEG_ILP)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define MVF_SEG(V_, M_) \
-    hipLaunchKernelGGL((segment_csr_kernel<V_, M_>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, lpr_log, out)
+    hipLaunchKernelGGL((segment_csr_kernel<V_, M_>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, out)
 #define MVF_SEG_MODE(V_)                                        \
     switch (reduce) {                                           \
     case MVF_REDUCE_SUM: MVF_SEG(V_, MVF_REDUCE_SUM); break;    \
