@@ -204,6 +204,68 @@ int mvf_segment_softmax_csr(
     const float *src, int32_t G, const int64_t *ptr, int64_t nseg, float eps,
     int32_t scaling, float *out, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* attentive pools: QKVBimodalCSRPool / GroupBimodalCSRPool / DeepSetFeat       */
+/* ------------------------------------------------------------------------- */
+
+/* One layer of MLP(channels, bias=False) in eval mode
+ * (core/common_modules/base_modules.py:38-48: Linear, FastBatchNorm1d
+ * :131-156, LeakyReLU(0.2)) or a plain nn.Linear (all bn_* NULL, act = 0).
+ * All pointers are device pointers. */
+typedef struct mvf_mlp_layer {
+    const float *weight;    /* [cout][cin], torch Linear.weight */
+    const float *bias;      /* [cout] or NULL */
+    const float *bn_weight; /* BatchNorm1d weight / bias / running_mean / running_var, */
+    const float *bn_bias;   /* [cout] each; all four NULL = no batch norm */
+    const float *bn_mean;
+    const float *bn_var;
+    float bn_eps;
+    float slope;            /* LeakyReLU negative slope, used when act != 0 */
+    int32_t cin, cout, act, pad_;
+} mvf_mlp_layer;
+
+/* A chain of 1..3 layers on the fp32 matrix cores, y = L_n(..L_1(in)), with
+ * in[row] = [xa[ga(row)] | xb[gb(row)]] (mode 0; xb may be NULL),
+ * xa + xb (mode 1) or [xa | xa + xb] (mode 2): the fusions of
+ * DeepSetFeat.forward (pooling.py:633-638, 671-680); ga / gb are optional row
+ * gathers (gather_csr of a per-segment tensor, pooling.py:825-853, or
+ * torch.repeat_interleave, pooling.py:489-501).  Every cout <= 64 and every
+ * cin after the first <= 64; the first cin is free.  `layers` is a host array. */
+int mvf_mlp_forward(
+    const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
+    const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
+    int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
+    float *out, int32_t ldo, void *stream);
+
+/* The attention tail shared by QKVBimodalCSRPool.forward (pooling.py:503-530)
+ * and GroupBimodalCSRPool.forward (pooling.py:284-300):
+ *   comp[r][g] = sum_k keys[r][g D + k] * queries[seg(r)][g D + k]   (/ sqrt(D) if dim_scaling)
+ *                (queries[r] instead when q_per_row, the use_mod_q case, pooling.py:487-494;
+ *                 keys == NULL: comp already holds the compatibilities)
+ *   att        = segment_softmax_csr(comp, ptr, scaling = group_scaling)
+ *   out[s][c]  = sum_r x_mod[r][c] * att[r][chan2group[c]]
+ *   gating:      gate[s][g] = tanh(relu(max_r comp[r][g] * gate_w[g] + gate_b[g])),
+ *                out[s][c] *= gate[s][chan2group[c]]               (Gating, pooling.py:702-723)
+ * comp / att are [rows][G], gate is [nseg][G]; they are outputs the caller
+ * may keep (the modules' save_last tensors).  chan2group may be NULL when G == 1. */
+int mvf_attention_pool(
+    const float *keys, int32_t ldk, const float *queries, int32_t ldq, int32_t q_per_row,
+    const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,
+    int32_t dim_scaling, int32_t group_scaling, float eps, const int32_t *chan2group,
+    const float *gate_w, const float *gate_b, int32_t gating,
+    float *comp, float *att, float *gate, float *out, void *stream);
+
+/* row -> segment index of a CSR pointer array (the dense index that
+ * pooling.py:306-308 builds with arange().repeat_interleave()). */
+int mvf_csr_row_segments(const int64_t *ptr, int64_t nseg, int32_t *row2seg, void *stream);
+
+/* HeuristicBimodalCSRPool.forward (pooling.py:129-152): out[s] = x_mod[row of
+ * the segment's largest (pick_max) or smallest value of feat], zeros for an
+ * empty segment; feat is one column of the mapping features, stride ldf. */
+int mvf_segment_pick(
+    const float *x_mod, int32_t C, const float *feat, int32_t ldf, const int64_t *ptr,
+    int64_t nseg, int32_t pick_max, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

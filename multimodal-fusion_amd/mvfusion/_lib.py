@@ -36,6 +36,18 @@ class MvfVisParams(C.Structure):
 
 assert C.sizeof(MvfView) == 128
 
+
+class MvfMlpLayer(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p),
+                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p),
+                ("bn_eps", C.c_float), ("slope", C.c_float),
+                ("cin", C.c_int32), ("cout", C.c_int32), ("act", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+assert C.sizeof(MvfMlpLayer) == 72
+
 _lock = threading.Lock()
 _lib = None
 
@@ -68,6 +80,12 @@ _SIGNATURES = {
     "mvf_segment_csr": (C.c_int, [_P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_gather_csr": (C.c_int, [_P, _I32, _P, _I64, _I64, _P, _P]),
     "mvf_segment_softmax_csr": (C.c_int, [_P, _I32, _P, _I64, _F, _I32, _P, _P]),
+    "mvf_mlp_forward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _I64, _P, _I32,
+                                  _P, _I32, _P]),
+    "mvf_attention_pool": (C.c_int, [_P, _I32, _P, _I32, _I32, _P, _I32, _P, _I64, _I64, _I32,
+                                     _I32, _I32, _I32, _F, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "mvf_csr_row_segments": (C.c_int, [_P, _I64, _P, _P]),
+    "mvf_segment_pick": (C.c_int, [_P, _I32, _P, _I32, _P, _I64, _I32, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -1,0 +1,228 @@
+"""Dense building blocks of the attentive pools: parameter containers with the
+reference's ``state_dict`` layout (``MLP`` / ``FastBatchNorm1d``,
+core/common_modules/base_modules.py:38-48,131-156) and the wrappers of the
+MFMA layer-chain, attention and row-segment kernels of libmvfusion.so.
+
+Inference only: the kernels implement eval-mode BatchNorm (running statistics)
+and record no autograd graph.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+_MAX_C = 64          # widest layer output (and non-first input) of one launch
+_MAX_LAYERS = 3
+
+
+class FastBatchNorm1d(nn.Module):
+    """Parameter container of base_modules.py:131-156 (``batch_norm`` child)."""
+
+    def __init__(self, num_features, momentum=0.1, **kwargs):
+        super().__init__()
+        self.batch_norm = nn.BatchNorm1d(num_features, momentum=momentum, **kwargs)
+
+    def forward(self, x):
+        raise RuntimeError(
+            "mvfusion.FastBatchNorm1d only holds parameters; the enclosing MLP runs "
+            "through mvfusion.dense.run_layers")
+
+
+def MLP(channels, activation=None, bn_momentum=0.1, bias=True):
+    """Same module tree (and state_dict keys) as base_modules.py:38-48."""
+    activation = nn.LeakyReLU(0.2, inplace=True) if activation is None else activation
+    return nn.Sequential(*[
+        nn.Sequential(
+            nn.Linear(channels[i - 1], channels[i], bias=bias),
+            FastBatchNorm1d(channels[i], momentum=bn_momentum),
+            activation)
+        for i in range(1, len(channels))])
+
+
+class LayerSpec:
+    """One Linear (+ eval BatchNorm) (+ LeakyReLU) layer as the kernel sees it."""
+
+    def __init__(self, linear, bn=None, slope=None):
+        self.weight = linear.weight.detach()
+        self.bias = None if linear.bias is None else linear.bias.detach()
+        self.bn = bn
+        self.slope = slope
+        self.cin, self.cout = int(linear.in_features), int(linear.out_features)
+
+    def tensors(self, lo=0, hi=None):
+        """(weight, bias, bn_weight, bn_bias, bn_mean, bn_var) of output
+        columns [lo, hi), contiguous float32."""
+        hi = self.cout if hi is None else hi
+        f = lambda t: None if t is None else t.detach()[lo:hi].float().contiguous()
+        bn = self.bn
+        return (f(self.weight), f(self.bias),
+                f(bn.weight) if bn is not None else None,
+                f(bn.bias) if bn is not None else None,
+                f(bn.running_mean) if bn is not None else None,
+                f(bn.running_var) if bn is not None else None)
+
+
+def mlp_layers(seq):
+    """LayerSpecs of an ``MLP(...)`` module tree."""
+    specs = []
+    for block in seq:
+        linear, fbn, act = block[0], block[1], block[2]
+        if not isinstance(act, nn.LeakyReLU):
+            raise NotImplementedError(f"mvfusion MLP kernels implement LeakyReLU, got {type(act)}")
+        specs.append(LayerSpec(linear, fbn.batch_norm, float(act.negative_slope)))
+    return specs
+
+
+def linear_layer(linear):
+    return LayerSpec(linear)
+
+
+def _check_eval(spec):
+    if spec.bn is not None and spec.bn.training:
+        raise RuntimeError(
+            "mvfusion pools run BatchNorm with running statistics only: call .eval() "
+            "(train-mode batch statistics and backward are not implemented)")
+
+
+def _launch(src, specs, cols, out, ldo_tensor):
+    """One mvf_mlp_forward launch.  src = (xa, ga, xb, gb, mode); specs = list
+    of (LayerSpec, lo, hi); out = tensor view whose first element is the
+    output's first column, ldo_tensor = row stride in floats."""
+    lib = L.load()
+    xa, ga, xb, gb, mode = src
+    keep = []
+    arr = (L.MvfMlpLayer * len(specs))()
+    for i, (sp, lo, hi) in enumerate(specs):
+        _check_eval(sp)
+        w, b, bw, bb, bm, bv = sp.tensors(lo, hi)
+        keep += [w, b, bw, bb, bm, bv]
+        a = arr[i]
+        a.weight, a.bias = w.data_ptr(), (b.data_ptr() if b is not None else None)
+        a.bn_weight = bw.data_ptr() if bw is not None else None
+        a.bn_bias = bb.data_ptr() if bb is not None else None
+        a.bn_mean = bm.data_ptr() if bm is not None else None
+        a.bn_var = bv.data_ptr() if bv is not None else None
+        a.bn_eps = float(sp.bn.eps) if sp.bn is not None else 0.0
+        a.slope = float(sp.slope) if sp.slope is not None else 0.0
+        a.cin, a.cout, a.act = sp.cin, hi - lo, int(sp.slope is not None)
+    rows = xa.shape[0] if ga is None else ga.shape[0]
+    dev = xa.device
+    with torch.cuda.device(dev):
+        L.check(lib.mvf_mlp_forward(
+            L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
+            L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
+            L.ptr(gb), mode, rows, arr, len(specs), L.ptr(out), ldo_tensor,
+            L.stream_ptr(dev)))
+    del keep
+
+
+def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0):
+    """y = specs[-1](... specs[0](input)) with input rows
+    [xa[ga] | xb[gb]] (mode 0), xa + xb (mode 1) or [xa | xa + xb] (mode 2).
+    Layers are packed into as few kernel launches as the width limits allow;
+    a layer wider than 64 outputs runs alone, 64 output columns per launch."""
+    def prep(t):
+        if t is None:
+            return None
+        if not t.is_cuda:
+            raise RuntimeError("mvfusion dense kernels run on a HIP device only "
+                               "(there is no CPU fallback)")
+        t = t.detach()
+        if t.dtype != torch.float32:
+            raise TypeError(f"mvfusion dense kernels expect float32, got {t.dtype}")
+        if t.dim() != 2:
+            raise ValueError("mvfusion dense kernels expect 2D [rows, channels] tensors")
+        return t if t.stride(1) == 1 else t.contiguous()
+
+    xa, xb = prep(xa), prep(xb)
+    for g in (gather_a, gather_b):
+        if g is not None and (g.dtype != torch.int32 or not g.is_cuda):
+            raise TypeError("row gathers must be int32 tensors on the HIP device")
+    rows = xa.shape[0] if gather_a is None else gather_a.shape[0]
+    src = (xa, gather_a, xb, gather_b, mode)
+    dev = xa.device
+    i = 0
+    x = None
+    while i < len(specs):
+        sp = specs[i]
+        if sp.cout > _MAX_C:
+            # a wide layer alone, 64 output columns per launch
+            out = torch.empty((rows, sp.cout), dtype=torch.float32, device=dev)
+            for lo in range(0, sp.cout, _MAX_C):
+                hi = min(sp.cout, lo + _MAX_C)
+                _launch(src, [(sp, lo, hi)], None, out[:, lo:], sp.cout)
+            i += 1
+        else:
+            group = [(sp, 0, sp.cout)]
+            j = i + 1
+            while (j < len(specs) and len(group) < _MAX_LAYERS and specs[j].cout <= _MAX_C
+                   and specs[j].cin <= _MAX_C):
+                group.append((specs[j], 0, specs[j].cout))
+                j += 1
+            cout = group[-1][0].cout
+            out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+            _launch(src, group, None, out, cout)
+            i = j
+        x = out
+        src = (x, None, None, None, 0)
+    return x
+
+
+def csr_row_segments(ptr, rows):
+    """int32 [rows]: segment index of every row of a CSR pointer array."""
+    lib = L.load()
+    out = torch.empty(rows, dtype=torch.int32, device=ptr.device)
+    if rows > 0:
+        with torch.cuda.device(ptr.device):
+            L.check(lib.mvf_csr_row_segments(
+                L.ptr(ptr), ptr.shape[0] - 1, L.ptr(out), L.stream_ptr(ptr.device)))
+    return out
+
+
+def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
+                   q_per_row=False, comp=None, nc_qk=1, dim_scaling=False,
+                   group_scaling=False, gate_w=None, gate_b=None, gating=False, eps=1e-12):
+    """Returns (x_pool, comp, att, gate).  Either ``keys``/``queries`` or
+    ``comp`` (the compatibilities) is given."""
+    lib = L.load()
+    dev = x_mod.device
+    rows, Cm = x_mod.shape
+    nseg = ptr.shape[0] - 1
+    G = int(num_groups)
+    if keys is None:
+        comp = comp.detach().float().contiguous().view(rows, G)
+    else:
+        comp = torch.empty((rows, G), dtype=torch.float32, device=dev)
+    att = torch.empty((rows, G), dtype=torch.float32, device=dev)
+    gate = torch.empty((nseg, G), dtype=torch.float32, device=dev) if gating else None
+    out = torch.empty((nseg, Cm), dtype=torch.float32, device=dev)
+    f = lambda t: None if t is None else t.detach().float().contiguous().view(-1)
+    gw, gb = f(gate_w), f(gate_b)
+    x_mod = x_mod.detach().contiguous()
+    if nseg > 0:
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_attention_pool(
+                L.ptr(keys), 0 if keys is None else keys.stride(0),
+                L.ptr(queries), 0 if queries is None else queries.stride(0), int(q_per_row),
+                L.ptr(x_mod), Cm, L.ptr(ptr), nseg, rows, G, int(nc_qk),
+                int(bool(dim_scaling)), int(bool(group_scaling)), float(eps),
+                L.ptr(chan2group), L.ptr(gw), L.ptr(gb), int(bool(gating)),
+                L.ptr(comp), L.ptr(att), L.ptr(gate), L.ptr(out), L.stream_ptr(dev)))
+    return out, comp, att, gate
+
+
+def segment_pick(x_mod, feat, ptr, pick_max):
+    lib = L.load()
+    dev = x_mod.device
+    x_mod = x_mod.detach().float().contiguous()
+    feat = feat.detach().float()
+    nseg = ptr.shape[0] - 1
+    out = torch.empty((nseg, x_mod.shape[1]), dtype=torch.float32, device=dev)
+    if nseg > 0:
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_segment_pick(
+                L.ptr(x_mod), x_mod.shape[1], L.ptr(feat), feat.stride(0), L.ptr(ptr), nseg,
+                int(bool(pick_max)), L.ptr(out), L.stream_ptr(dev)))
+    return out

@@ -6,10 +6,13 @@ kernels of libmvfusion.so instead of ``torch_scatter``.
 Reference lines (DeepViewAgg-Wildscenes/torch_points3d/modules/multimodal/
 pooling.py): BimodalCSRPool :14-71, segment_softmax_csr :770-822, gather_csr
 :825-853, segment_gather_csr :856-868, expand_group_feat :760-767,
-group_sizes :749-757.  Forward (inference) only: no autograd graph is recorded
-through the HIP kernels.
+group_sizes :749-757, HeuristicBimodalCSRPool :74-156, GroupBimodalCSRPool :159-319,
+QKVBimodalCSRPool :322-551, MinMaxDiffSetFeat :554-601, DeepSetFeat :604-685,
+MLPSetFeat :688-699, Gating :702-727.  Forward (inference) only: no autograd
+graph is recorded through the HIP kernels.
 """
 import math
+import sys
 from abc import ABC
 
 import torch
@@ -159,3 +162,435 @@ class BimodalCSRPool(nn.Module, ABC):
                 csr_idx[1:] - csr_idx[:-1])
             self._last_view_num = csr_idx[1:] - csr_idx[:-1]
         return x_pool
+
+
+# --------------------------------------------------------------------------- #
+# attentive pools (pooling.py:74-727)                                          #
+# --------------------------------------------------------------------------- #
+from . import dense as _dense                      # noqa: E402
+from .dense import MLP                             # noqa: E402,F401  (state_dict-compatible container)
+
+_local_modules = sys.modules[__name__]
+
+
+def _device_ptr(x, csr_idx):
+    if not x.is_cuda:
+        raise RuntimeError(
+            "mvfusion pooling runs on a HIP device only: move the features and "
+            "the CSR pointers to the GPU (there is no CPU fallback).")
+    return csr_idx.to(device=x.device, dtype=torch.int64).contiguous()
+
+
+def _last_idx(csr_idx, device):
+    return torch.arange(csr_idx.shape[0] - 1, device=device).repeat_interleave(
+        csr_idx[1:] - csr_idx[:-1])
+
+
+def _set_num(ptr):
+    # Heuristic to normalize in [0,1] (pooling.py:590,675)
+    return torch.sqrt(1 / (ptr[1:] - ptr[:-1] + 1e-3)).float()
+
+
+def nearest_power_of_2(x, min_power=16):
+    """pooling.py:730-746."""
+    x = int(x)
+    if x < min_power:
+        return min_power
+    previous_power = 2 ** ((x - 1).bit_length() - 1)
+    next_power = 2 ** (x - 1).bit_length()
+    if x - previous_power < next_power - x:
+        return previous_power
+    return next_power
+
+
+class HeuristicBimodalCSRPool(nn.Module, ABC):
+    """Selects the modality features of the view with the largest / smallest
+    value of one handcrafted mapping feature (pooling.py:74-156).  Ties go to
+    the first row of the group."""
+
+    _MODES = ['max', 'min']
+    _FEATURES = [
+        'normalized_depth', 'linearity', 'planarity', 'scattering',
+        'orientation_to_the_surface', 'normalized_pixel_height', 'density',
+        'occlusion']
+
+    def __init__(self, mode='max', feat=0, save_last=False, **kwargs):
+        super(HeuristicBimodalCSRPool, self).__init__()
+        assert mode in self._MODES, \
+            f"Unsupported mode '{mode}'. Expected one of: {self._MODES}."
+        self._mode = mode
+        feat = self._FEATURES.index(feat) if isinstance(feat, str) else feat
+        assert feat < len(self._FEATURES), \
+            f"Feat={feat} is too large. Expected feat<{len(self._FEATURES)}."
+        self._feat = feat
+        self.save_last = save_last
+        self._last_x_map = None
+        self._last_x_mod = None
+        self._last_idx = None
+        self._last_view_num = None
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        ptr = _device_ptr(x_mod, csr_idx)
+        x_pool = _dense.segment_pick(x_mod, x_map[:, self._feat], ptr, self._mode == 'max')
+        if self.save_last:
+            self._last_x_map = x_map
+            self._last_x_mod = x_mod
+            self._last_idx = _last_idx(csr_idx, x_mod.device)
+            self._last_view_num = csr_idx[1:] - csr_idx[:-1]
+        return x_pool
+
+    def extra_repr(self) -> str:
+        return f'mode={self._mode}, feat={self._FEATURES[self._feat]}, ' \
+               f'save_last={self.save_last}'
+
+
+class MinMaxDiffSetFeat(nn.Module, ABC):
+    """Element-wise set features from difference-to-min / -max and set size
+    (pooling.py:554-601)."""
+
+    def __init__(self, d_in, d_out, use_min=True, use_max=True, use_num=False, **kwargs):
+        super(MinMaxDiffSetFeat, self).__init__()
+        self.d_in = d_in
+        self.d_out = d_out
+        self.use_min = use_min
+        self.use_max = use_max
+        self.use_num = use_num
+        in_mlp = d_in * (1 + self.use_min + self.use_max) + self.use_num
+        self.mlp = MLP([in_mlp, d_out, d_out], bias=False)
+
+    def embed(self, x, ptr, row2seg, tail=()):
+        parts = [x]
+        if self.use_min:
+            parts.append(x - segment_gather_csr(x, ptr, reduce='min'))
+        if self.use_max:
+            parts.append(x - segment_gather_csr(x, ptr, reduce='max'))
+        if self.use_num:
+            num = _set_num(ptr)
+            parts.append(num.repeat_interleave(ptr[1:] - ptr[:-1]).view(-1, 1))
+        x_out = torch.cat(parts, dim=1) if len(parts) > 1 else x
+        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x_out)
+
+    def forward(self, x, csr_idx):
+        ptr = _device_ptr(x, csr_idx)
+        return self.embed(x, ptr, None)
+
+    def extra_repr(self) -> str:
+        repr_attr = ['use_min', 'use_max', 'use_num']
+        return "\n".join([f'{a}={getattr(self, a)}' for a in repr_attr])
+
+
+class DeepSetFeat(nn.Module, ABC):
+    """Element-wise set features from shared learned features
+    (pooling.py:604-685)."""
+
+    _POOLING_MODES = ['max', 'mean', 'min', 'sum']
+    _FUSION_MODES = ['residual', 'concatenation', 'both']
+
+    def __init__(self, d_in, d_out, pool='max', fusion='concatenation', use_num=False, **kwargs):
+        super(DeepSetFeat, self).__init__()
+        pool = pool.split('_')
+        assert all([p in self._POOLING_MODES for p in pool]), \
+            f"Unsupported pool='{pool}'. Expected elements of: " \
+            f"{self._POOLING_MODES}"
+        self.pool = pool
+        if fusion not in self._FUSION_MODES:
+            raise NotImplementedError(
+                f"Unknown fusion='{fusion}'. Please choose among "
+                f"supported modes: {self._FUSION_MODES}.")
+        self.fusion = fusion
+        self.d_in = d_in
+        self.d_out = d_out
+        self.use_num = use_num
+        self.mlp_elt_1 = MLP([d_in, d_out, d_out], bias=False)
+        in_set_mlp = d_out * len(self.pool) + self.use_num
+        self.mlp_set = MLP([in_set_mlp, d_out, d_out], bias=False)
+        in_last_mlp = d_out if fusion == 'residual' else d_out * 2
+        self.mlp_elt_2 = MLP([in_last_mlp, d_out, d_out], bias=False)
+
+    def embed(self, x, ptr, row2seg, tail=()):
+        """forward with optional extra layers (the pools' K / E_score Linear)
+        fused behind mlp_elt_2."""
+        if row2seg is None:
+            row2seg = _dense.csr_row_segments(ptr, x.shape[0])
+        x1 = _dense.run_layers(_dense.mlp_layers(self.mlp_elt_1), x)
+        sets = [segment_csr(x1, ptr, reduce=p) for p in self.pool]
+        if self.use_num:
+            sets.append(_set_num(ptr).view(-1, 1))
+        x_set = torch.cat(sets, dim=-1) if len(sets) > 1 else sets[0]
+        x_set = _dense.run_layers(_dense.mlp_layers(self.mlp_set), x_set)
+        mode = {'concatenation': 0, 'residual': 1, 'both': 2}[self.fusion]
+        # gather_csr(x_set) and the fusion happen while mlp_elt_2 loads its input
+        return _dense.run_layers(
+            _dense.mlp_layers(self.mlp_elt_2) + list(tail), x1, None, x_set, row2seg, mode)
+
+    def forward(self, x, csr_idx):
+        ptr = _device_ptr(x, csr_idx)
+        return self.embed(x, ptr, None)
+
+    def extra_repr(self) -> str:
+        repr_attr = ['pool', 'fusion', 'use_num']
+        return "\n".join([f'{a}={getattr(self, a)}' for a in repr_attr])
+
+
+class MLPSetFeat(nn.Module, ABC):
+    """Element-wise set features with a simple MLP (pooling.py:688-699)."""
+
+    def __init__(self, d_in, d_out, **kwargs):
+        super(MLPSetFeat, self).__init__()
+        self.d_in = d_in
+        self.d_out = d_out
+        self.mlp = MLP([d_in, d_out, d_out], bias=False)
+
+    def embed(self, x, ptr, row2seg, tail=()):
+        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x)
+
+    def forward(self, x, csr_idx):
+        return self.embed(x, None, None)
+
+
+class Gating(nn.Module):
+    """Rectified-tanh gating mechanism with learnable linear correction
+    (pooling.py:702-727).  Inside the pools the gate is evaluated by the
+    attention kernel; this forward serves direct calls."""
+
+    def __init__(self, num_groups, weight=True, bias=True, activation='tanh+'):
+        super(Gating, self).__init__()
+        self.num_groups = num_groups
+        self.weight = nn.Parameter(torch.ones(1, num_groups)) if weight else None
+        self.bias = nn.Parameter(torch.zeros(1, num_groups)) if bias else None
+        if activation not in ('tanh+', 'sigmoid'):
+            raise ValueError(f"Activation '{activation}' not supported for Gating")
+        self._activation = activation
+
+    def forward(self, x):
+        if self.weight is not None:
+            x = x * self.weight
+        if self.bias is not None:
+            x = x + self.bias
+        x = torch.tanh(torch.relu(x)) if self._activation == 'tanh+' else torch.sigmoid(x)
+        return x.view(-1, self.num_groups).squeeze(1)
+
+    def extra_repr(self) -> str:
+        return f'num_groups={self.num_groups}, ' \
+            f'weight={self.weight is not None}, bias={self.bias is not None}'
+
+
+_MAP_ENCODERS = {'DeepSetFeat': DeepSetFeat, 'MinMaxDiffSetFeat': MinMaxDiffSetFeat,
+                 'MLPSetFeat': MLPSetFeat}
+
+
+class _AttentivePool(nn.Module, ABC):
+    """What GroupBimodalCSRPool and QKVBimodalCSRPool share."""
+
+    def _chan2group(self, device):
+        if self.num_groups == 1:
+            return None
+        cache = self.__dict__.setdefault('_c2g', {})
+        key = str(device)
+        if key not in cache:
+            if self.num_groups < self.out_mod:
+                sizes = group_sizes(self.out_mod, self.num_groups)
+                c2g = torch.arange(self.num_groups).repeat_interleave(sizes)
+            else:
+                c2g = torch.arange(self.out_mod)
+            cache[key] = c2g.to(device=device, dtype=torch.int32)
+        return cache[key]
+
+    def _check_mode(self):
+        if self.training:
+            raise RuntimeError(
+                f"{type(self).__name__}: only inference is implemented (BatchNorm with "
+                f"running statistics, no backward): call .eval() first")
+        if self.G is not None and self.G._activation != 'tanh+':
+            raise NotImplementedError("the attention kernel implements the 'tanh+' gate only")
+
+
+class GroupBimodalCSRPool(_AttentivePool):
+    """Attention over the views of a point from mapping features only
+    (pooling.py:159-319)."""
+
+    def __init__(
+            self, in_map=None, in_mod=None, out_mod=None, num_groups=1,
+            use_mod=False, gating=True, group_scaling=True, save_last=False,
+            nc_inner=32, map_encoder='DeepSetFeat', **kwargs):
+        super(GroupBimodalCSRPool, self).__init__()
+        self.nc_inner = nc_inner
+        self.save_last = save_last
+        self._last_x_map = None
+        self._last_x_mod = None
+        self._last_idx = None
+        self._last_view_num = None
+        self._last_C = None
+        self._last_A = None
+        self._last_G = None
+        assert 1 <= num_groups <= in_mod, \
+            f"Number of groups must be between 1 and in_mod={in_mod}."
+        out_mod = in_mod if out_mod is None else out_mod
+        self.in_mod = in_mod
+        self.out_mod = out_mod
+        self.use_mod = use_mod
+        self.num_groups = num_groups
+        self.group_scaling = group_scaling
+        self.E_map = _MAP_ENCODERS[map_encoder](in_map, nc_inner, **kwargs)
+        self.E_mod = MLP([in_mod, out_mod, out_mod], bias=False)
+        if self.use_mod:
+            in_mix = nc_inner + out_mod
+            out_mix = nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.E_score = nn.Linear(nc_inner, num_groups, bias=True)
+        self.G = Gating(num_groups, bias=True) if gating else None
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        """
+        :param x_main: N x F_main
+        :param x_mod: V x F_mod
+        :param x_map: V x F_map
+        :param csr_idx:
+        :return: x_pool
+        """
+        self._check_mode()
+        ptr = _device_ptr(x_mod, csr_idx)
+        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
+        score = [_dense.linear_layer(self.E_score)]
+        x_mod = _dense.run_layers(_dense.mlp_layers(self.E_mod), x_mod)
+        if self.use_mod or self.save_last:
+            x_map = self.E_map.embed(x_map, ptr, row2seg)
+            if self.use_mod:
+                comp = _dense.run_layers(_dense.mlp_layers(self.E_mix) + score, x_map, None, x_mod)
+            else:
+                comp = _dense.run_layers(score, x_map)
+        else:
+            comp = self.E_map.embed(x_map, ptr, row2seg, tail=score)
+        x_pool, comp, att, gate = _dense.attention_pool(
+            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), comp=comp,
+            group_scaling=self.group_scaling,
+            gate_w=None if self.G is None else self.G.weight,
+            gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
+        if self.save_last:
+            self._last_x_map = x_map
+            self._last_x_mod = x_mod
+            self._last_idx = _last_idx(csr_idx, x_mod.device)
+            self._last_view_num = csr_idx[1:] - csr_idx[:-1]
+            self._last_C = comp
+            self._last_A = att
+            if self.G:
+                self._last_G = gate.view(-1, self.num_groups).squeeze(1)
+        return x_pool
+
+    def extra_repr(self) -> str:
+        repr_attr = ['num_groups', 'use_mod', 'group_scaling', 'save_last']
+        return "\n".join([f'{a}={getattr(self, a)}' for a in repr_attr])
+
+
+class QKVBimodalCSRPool(_AttentivePool):
+    """Key-query attention over the views of a point: keys from the mapping
+    features, queries from the main modality (pooling.py:322-551)."""
+
+    def __init__(
+            self, in_main=None, in_map=None, in_mod=None, out_mod=None,
+            num_groups=1, use_mod_q=False, use_mod_k=False, nc_qk=8,
+            gating=True, dim_scaling=True, group_scaling=False, debug=False,
+            save_last=False, nc_inner=32, map_encoder='DeepSetFeat', **kwargs):
+        super(QKVBimodalCSRPool, self).__init__()
+        self.nc_inner = nc_inner
+        self.save_last = save_last
+        self._last_x_map = None
+        self._last_x_mod = None
+        self._last_idx = None
+        self._last_view_num = None
+        self._last_Q = None
+        self._last_K = None
+        self._last_C = None
+        self._last_A = None
+        self._last_G = None
+        self.debug = debug
+        if debug:
+            raise NotImplementedError(
+                "QKVBimodalCSRPool(debug=True) replaces its inputs by random numbers "
+                "(pooling.py:463-468); not reproduced")
+        assert 1 <= num_groups <= in_mod, \
+            f"Number of groups must be between 1 and in_mod={in_mod}."
+        out_mod = in_mod if out_mod is None else out_mod
+        self.in_mod = in_mod
+        self.out_mod = out_mod
+        self.nc_qk = nc_qk
+        self.use_mod_q = use_mod_q
+        self.use_mod_k = use_mod_k
+        self.num_groups = num_groups
+        self.dim_scaling = dim_scaling
+        self.group_scaling = group_scaling
+        self.E_main = MLP([in_main, nc_inner, nc_inner], bias=False)
+        self.E_map = _MAP_ENCODERS[map_encoder](in_map, nc_inner, **kwargs)
+        self.E_mod = MLP([in_mod, out_mod, out_mod], bias=False)
+        if self.use_mod_q:
+            in_mix = nc_inner + out_mod
+            out_mix = nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix_Q = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.Q = nn.Linear(nc_inner, nc_qk * num_groups, bias=True)
+        if self.use_mod_k:
+            in_mix = nc_inner + in_mod
+            out_mix = nc_inner
+            mid_mix = nearest_power_of_2((in_mix + out_mix) / 2, out_mix * 2)
+            self.E_mix_K = MLP([in_mix, mid_mix, out_mix], bias=False)
+        self.K = nn.Linear(nc_inner, nc_qk * num_groups, bias=True)
+        self.G = Gating(num_groups, bias=True) if gating else None
+
+    def forward(self, x_main, x_mod, x_map, csr_idx):
+        """
+        :param x_main: N x F_main
+        :param x_mod: V x F_mod
+        :param x_map: V x F_map
+        :param csr_idx:
+        :return: x_pool
+        """
+        self._check_mode()
+        ptr = _device_ptr(x_mod, csr_idx)
+        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
+        k_lin, q_lin = [_dense.linear_layer(self.K)], [_dense.linear_layer(self.Q)]
+
+        # values : V x F_mod
+        x_mod = _dense.run_layers(_dense.mlp_layers(self.E_mod), x_mod)
+
+        # keys : V x (D x num_groups), the K Linear fused behind the map encoder
+        if self.use_mod_k or self.save_last:
+            x_map = self.E_map.embed(x_map, ptr, row2seg)
+            if self.use_mod_k:
+                keys = _dense.run_layers(_dense.mlp_layers(self.E_mix_K) + k_lin, x_map, None, x_mod)
+            else:
+                keys = _dense.run_layers(k_lin, x_map)
+        else:
+            keys = self.E_map.embed(x_map, ptr, row2seg, tail=k_lin)
+
+        # queries : N x (D x num_groups), or V x ... when the modality is mixed in
+        if self.use_mod_q:
+            x_main = _dense.run_layers(_dense.mlp_layers(self.E_main), x_main)
+            queries = _dense.run_layers(
+                _dense.mlp_layers(self.E_mix_Q) + q_lin, x_main, row2seg, x_mod)
+        else:
+            queries = _dense.run_layers(_dense.mlp_layers(self.E_main) + q_lin, x_main)
+
+        x_pool, comp, att, gate = _dense.attention_pool(
+            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), keys=keys,
+            queries=queries, q_per_row=self.use_mod_q, nc_qk=self.nc_qk,
+            dim_scaling=self.dim_scaling, group_scaling=self.group_scaling,
+            gate_w=None if self.G is None else self.G.weight,
+            gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
+
+        if self.save_last:
+            self._last_x_map = x_map
+            self._last_x_mod = x_mod
+            self._last_idx = _last_idx(csr_idx, x_mod.device)
+            self._last_view_num = csr_idx[1:] - csr_idx[:-1]
+            self._last_K = keys
+            self._last_Q = queries if self.use_mod_q else gather_csr(queries, ptr)
+            self._last_C = comp
+            self._last_A = att
+            if self.G:
+                self._last_G = gate.view(-1, self.num_groups).squeeze(1)
+        return x_pool
+
+    def extra_repr(self) -> str:
+        repr_attr = ['dim_scaling', 'group_scaling', 'save_last']
+        return "\n".join([f'{a}={getattr(self, a)}' for a in repr_attr])

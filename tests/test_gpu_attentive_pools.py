@@ -1,0 +1,173 @@
+"""GPU parity of the attentive pools (QKVBimodalCSRPool, GroupBimodalCSRPool,
+DeepSetFeat, HeuristicBimodalCSRPool) through the C ABI: against the golden
+vectors captured from the reference modules, and against the CPU oracle on
+larger seeded inputs and on the option combinations the fixtures do not cover.
+Tolerance: 1e-5 relative to the output scale (fp32 GEMMs; the summation order
+of the reference's BLAS is not part of its contract)."""
+import numpy as np
+import pytest
+import torch
+
+from mvfusion import pooling
+
+import mvf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _sd(g):
+    return {k[3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd.")}
+
+
+def _close(got, want, rtol=1e-5):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    scale = max(float(np.abs(want).max()), 1e-30)
+    np.testing.assert_allclose(got, want.reshape(got.shape), rtol=rtol, atol=rtol * scale)
+
+
+@pytest.mark.parametrize("name", ["qkv_default", "qkv_groups4", "qkv_nogate"])
+def test_qkv_pool_golden(golden, name):
+    g = golden(name)
+    mod = pooling.QKVBimodalCSRPool(
+        in_main=g["x_main"].shape[1], in_map=g["x_map"].shape[1], in_mod=g["x_mod"].shape[1],
+        out_mod=g["x_mod"].shape[1], num_groups=int(g["num_groups"]), nc_qk=int(g["nc_qk"]),
+        gating=bool(g["gating"]), dim_scaling=bool(g["dim_scaling"]),
+        group_scaling=bool(g["group_scaling"]), use_num=bool(g["use_num"]), save_last=True,
+        map_encoder="DeepSetFeat")
+    missing = mod.load_state_dict(_sd(g), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    mod = mod.to(DEV).eval()
+    out = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
+    _close(out, g["x_pool"])
+    _close(mod._last_C, g["C"], rtol=1e-4)
+    _close(mod._last_A, g["A"], rtol=1e-4)
+    if bool(g["gating"]):
+        _close(mod._last_G, g["G"], rtol=1e-4)
+    # the fused path (no save_last: K behind the map encoder) gives the same result
+    mod.save_last = False
+    out2 = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
+    assert torch.equal(out, out2)
+
+
+def test_group_pool_golden(golden):
+    g = golden("group_pool")
+    mod = pooling.GroupBimodalCSRPool(
+        in_map=g["x_map"].shape[1], in_mod=g["x_mod"].shape[1], out_mod=g["x_mod"].shape[1],
+        num_groups=int(g["num_groups"]), gating=bool(g["gating"]),
+        group_scaling=bool(g["group_scaling"]), use_num=bool(g["use_num"]),
+        map_encoder="DeepSetFeat")
+    mod.load_state_dict(_sd(g), strict=True)
+    mod = mod.to(DEV).eval()
+    out = mod(None, T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
+    _close(out, g["x_pool"])
+
+
+def _random_module(mod, seed):
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.weight.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=gen) * 0.2)
+        if getattr(mod, "G", None) is not None:
+            mod.G.weight.copy_(torch.rand(mod.G.weight.shape, generator=gen) + 0.5)
+            mod.G.bias.copy_(torch.randn(mod.G.bias.shape, generator=gen) * 0.1)
+    return mod
+
+
+def _np_sd(mod):
+    return {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+
+
+def _ptr(rng, n, mean):
+    counts = np.minimum(rng.poisson(mean, n), 32)
+    counts[rng.random(n) < 0.05] = 0
+    return np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+
+
+@pytest.mark.parametrize("groups,pool,fusion,in_mod,out_mod", [
+    (1, "max", "concatenation", 64, 64),
+    (8, "max_mean", "residual", 64, 64),
+    (13, "min", "both", 13, 13),          # odd widths, one group per channel
+    (2, "max", "concatenation", 160, 96),  # layers wider than one launch
+])
+def test_qkv_pool_vs_oracle(groups, pool, fusion, in_mod, out_mod):
+    rng = np.random.default_rng(5)
+    N = 20000
+    ptr = _ptr(rng, N, 4)
+    Vw = int(ptr[-1])
+    x_main = rng.random((N, 24)).astype(np.float32)
+    x_mod = rng.random((Vw, in_mod)).astype(np.float32)
+    x_map = rng.random((Vw, 8)).astype(np.float32)
+    torch.manual_seed(groups)
+    mod = _random_module(pooling.QKVBimodalCSRPool(
+        in_main=24, in_map=8, in_mod=in_mod, out_mod=out_mod, num_groups=groups, nc_qk=8,
+        gating=True, dim_scaling=True, group_scaling=True, pool=pool, fusion=fusion,
+        use_num=True), 3)
+    want = orc.qkv_pool(x_main, x_mod, x_map, ptr, _np_sd(mod), num_groups=groups, nc_qk=8,
+                        gating=True, dim_scaling=True, group_scaling=True, use_num=True,
+                        pool=tuple(pool.split("_")), fusion=fusion)
+    out = mod.to(DEV).eval()(T(x_main), T(x_mod), T(x_map), T(ptr))
+    assert out.shape == (N, out_mod)
+    _close(out, want)
+
+
+def test_group_pool_vs_oracle_and_empty():
+    rng = np.random.default_rng(6)
+    N = 5000
+    ptr = _ptr(rng, N, 3)
+    Vw = int(ptr[-1])
+    x_mod = rng.random((Vw, 32)).astype(np.float32)
+    x_map = rng.random((Vw, 8)).astype(np.float32)
+    torch.manual_seed(1)
+    mod = _random_module(pooling.GroupBimodalCSRPool(
+        in_map=8, in_mod=32, num_groups=4, gating=True, group_scaling=True), 4)
+    want = orc.group_pool(x_mod, x_map, ptr, _np_sd(mod), num_groups=4, gating=True,
+                          group_scaling=True)
+    mod = mod.to(DEV).eval()
+    _close(mod(None, T(x_mod), T(x_map), T(ptr)), want)
+    # all groups empty: zeros of the right shape
+    z = mod(None, T(x_mod[:0]), T(x_map[:0]), T(np.zeros(8, np.int64)))
+    assert z.shape == (7, 32) and float(z.abs().max()) == 0.0
+
+
+def test_deep_set_feat_vs_oracle():
+    rng = np.random.default_rng(7)
+    ptr = _ptr(rng, 3000, 5)
+    x = rng.random((int(ptr[-1]), 8)).astype(np.float32)
+    torch.manual_seed(2)
+    mod = _random_module(pooling.DeepSetFeat(8, 32, pool="max", fusion="concatenation"), 5)
+    sd = {"E." + k: v for k, v in _np_sd(mod).items()}
+    want = orc.deep_set_feat(x, ptr, sd, "E")
+    _close(mod.to(DEV).eval()(T(x), T(ptr)), want)
+
+
+def test_heuristic_pool_and_modes():
+    rng = np.random.default_rng(8)
+    ptr = _ptr(rng, 2000, 3)
+    Vw = int(ptr[-1])
+    x_mod = rng.random((Vw, 16)).astype(np.float32)
+    x_map = rng.random((Vw, 8)).astype(np.float32)
+    for mode in ("max", "min"):
+        out = pooling.HeuristicBimodalCSRPool(mode=mode, feat="planarity")(
+            None, T(x_mod), T(x_map), T(ptr)).cpu().numpy()
+        want = np.zeros((2000, 16), np.float32)
+        for s in range(2000):
+            a, b = ptr[s], ptr[s + 1]
+            if b > a:
+                f = x_map[a:b, 2]
+                want[s] = x_mod[a + (np.argmax(f) if mode == "max" else np.argmin(f))]
+        np.testing.assert_array_equal(out, want)
+
+
+def test_training_mode_and_cpu_inputs_raise():
+    mod = pooling.QKVBimodalCSRPool(in_main=4, in_map=4, in_mod=4)
+    x = torch.zeros(2, 4, device=DEV)
+    with pytest.raises(RuntimeError):
+        mod.to(DEV)(x, x, x, torch.tensor([0, 1, 2], device=DEV))
+    with pytest.raises(RuntimeError):
+        mod.eval()(x.cpu(), x.cpu(), x.cpu(), torch.tensor([0, 1, 2]))
