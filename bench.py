@@ -30,6 +30,7 @@ from mvfusion.images import SameSettingImageData    # noqa: E402
 from mvfusion.pooling import segment_csr            # noqa: E402
 from mvfusion.transforms import MapImages, kdtree_order  # noqa: E402
 from mvfusion import visibility as visibility_module     # noqa: E402
+from mvfusion.distributed import gather_pooled           # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec peak
 VIS = dict(voxel=0.05, r_max=20, r_min=0, k_swell=1.5, d_swell=1e6, exact=True,
@@ -171,10 +172,7 @@ def main():
         out = step()
     if dist is not None:
         # the path's only exchange: final gather of pooled features and labels
-        feats_all = torch.empty((world * N, 2 * C_feat), device=device)
-        labels_all = torch.empty(world * N, dtype=labels.dtype, device=device)
-        dist.all_gather_into_tensor(feats_all, torch.cat(out[:2], dim=1))
-        dist.all_gather_into_tensor(labels_all, labels)
+        feats_all, labels_all, _ = gather_pooled(torch.cat(out[:2], dim=1), labels)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

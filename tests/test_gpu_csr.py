@@ -1,0 +1,85 @@
+"""GPU parity of the CSR containers next to the hot path: lexicographic ops,
+ImageMapping.from_dense, CSRBatch / ImageMappingBatch, against the golden
+vectors captured from the reference (integer outputs bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from mvfusion import mapping as M
+from mvfusion.csr import CSRData
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+N = lambda t: t.detach().cpu().numpy()
+
+
+def canonical_pixels(view_ptr, pixels):
+    # the reference leaves the pixel order inside a (point, image) group to an
+    # unstable argsort: compare groups as sorted sets
+    out = pixels.copy()
+    for a, b in zip(view_ptr[:-1], view_ptr[1:]):
+        if b - a > 1:
+            seg = pixels[a:b]
+            out[a:b] = seg[np.lexsort((seg[:, 1], seg[:, 0]))]
+    return out
+
+
+def test_lexops_golden(golden):
+    g = golden("lexops")
+    a, b, c = T(g["a"]), T(g["b"]), T(g["c"])
+    assert np.array_equal(N(M.lexargunique(a, b, c)), g["argunique"])
+    assert np.array_equal(N(M.lexunique(a)), g["unique_a"])
+    assert M.lexargunique(a[:0], b[:0]).shape[0] == 0
+    mine = N(M.lexargsort(a, b))
+    for arr in (g["a"], g["b"]):
+        assert np.array_equal(arr[mine], arr[g["argsort"]])
+
+
+def test_from_dense_golden(golden):
+    g = golden("from_dense")
+    m = M.ImageMapping.from_dense(
+        T(g["point_ids"]), T(g["image_ids"]), T(g["pixels"]), T(g["features"]),
+        num_points=int(g["num_points"]))
+    assert np.array_equal(N(m.pointers), g["pointers"])
+    assert np.array_equal(N(m.images), g["images"])
+    assert np.array_equal(N(m.atomic_csr_indexing), g["view_pointers"])
+    assert m.pixels.dtype == torch.int16
+    assert np.array_equal(canonical_pixels(g["view_pointers"], N(m.pixels)),
+                          canonical_pixels(g["view_pointers"], g["out_pixels"]))
+    np.testing.assert_allclose(N(m.features), g["out_features"], rtol=1e-6, atol=1e-7)
+    # the index tuple for x[B, C, H, W] (core/multimodal/image.py:1881-1895)
+    ib, _, ih, iw = m.feature_map_indexing
+    sizes = np.diff(g["view_pointers"])
+    assert np.array_equal(N(ib), np.repeat(g["images"], sizes))
+    assert np.array_equal(N(iw), N(m.pixels)[:, 0]) and np.array_equal(N(ih), N(m.pixels)[:, 1])
+
+
+def test_csr_batch_golden(golden):
+    g = golden("csr_batch")
+    items = [M.ImageMapping.from_dense(
+        T(g[f"pid{k}"]), T(g[f"iid{k}"]), T(g[f"pix{k}"]), T(g[f"feat{k}"]),
+        num_points=int(g["num_points"])) for k in range(3)]
+    batch = M.ImageMappingBatch.from_csr_list(items)
+    assert np.array_equal(N(batch.pointers), g["pointers"])
+    assert np.array_equal(N(batch.images), g["images"])
+    assert np.array_equal(N(batch.atomic_csr_indexing), g["view_pointers"])
+    assert np.array_equal(canonical_pixels(g["view_pointers"], N(batch.pixels)),
+                          canonical_pixels(g["view_pointers"], g["pixels"]))
+    np.testing.assert_allclose(N(batch.features), g["features"], rtol=1e-6, atol=1e-7)
+    # round trip (core/multimodal/image.py:2360-2400)
+    back = batch.to_csr_list()
+    assert len(back) == 3
+    for a, b in zip(items, back):
+        assert torch.equal(a.pointers, b.pointers) and torch.equal(a.images, b.images)
+        assert torch.equal(a.pixels, b.pixels)
+
+
+def test_csr_docstring_case():
+    # csr.py:26-41: dense indices -> pointers, empty groups inserted
+    idx = torch.tensor([0, 0, 1, 3, 3, 3], device=DEV)
+    val = torch.arange(6, device=DEV)
+    c = CSRData(idx, val, dense=True)
+    assert N(c.pointers).tolist() == [0, 2, 3, 6]
+    c = c.insert_empty_groups(torch.tensor([0, 1, 3], device=DEV), num_groups=5)
+    assert N(c.pointers).tolist() == [0, 2, 3, 3, 6, 6]
