@@ -240,8 +240,9 @@ int mvf_mlp_forward(
 /* The attention tail shared by QKVBimodalCSRPool.forward (pooling.py:503-530)
  * and GroupBimodalCSRPool.forward (pooling.py:284-300):
  *   comp[r][g] = sum_k keys[r][g D + k] * queries[seg(r)][g D + k]   (/ sqrt(D) if dim_scaling)
- *                (queries[r] instead when q_per_row, the use_mod_q case, pooling.py:487-494;
- *                 keys == NULL: comp already holds the compatibilities)
+ *                (seg(r) = row2seg[r]; row2seg == NULL: queries has one row per key row, the
+ *                 use_mod_q case, pooling.py:487-494; keys == NULL: comp already holds the
+ *                 compatibilities)
  *   att        = segment_softmax_csr(comp, ptr, scaling = group_scaling)
  *   out[s][c]  = sum_r x_mod[r][c] * att[r][chan2group[c]]
  *   gating:      gate[s][g] = tanh(relu(max_r comp[r][g] * gate_w[g] + gate_b[g])),
@@ -249,7 +250,7 @@ int mvf_mlp_forward(
  * comp / att are [rows][G], gate is [nseg][G]; they are outputs the caller
  * may keep (the modules' save_last tensors).  chan2group may be NULL when G == 1. */
 int mvf_attention_pool(
-    const float *keys, int32_t ldk, const float *queries, int32_t ldq, int32_t q_per_row,
+    const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
     const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,
     int32_t dim_scaling, int32_t group_scaling, float eps, const int32_t *chan2group,
     const float *gate_w, const float *gate_b, int32_t gating,

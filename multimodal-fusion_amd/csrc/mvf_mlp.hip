@@ -3,16 +3,22 @@
 // fp32 matrix cores, the query/key softmax and the attention-weighted segment
 // sum.
 //
-// MLP chain.  A wave owns a tile of 32 rows; its activations live in a private
-// LDS tile between layers, so a chain of up to three layers reads its input
-// once from HBM and writes its output once.  Every layer is a sequence of
-// v_mfma_f32_32x32x2_f32: A = the activation tile (lane l holds row l & 31,
-// k = l >> 5), B = the transposed weights in LDS (lane l holds k = l >> 5,
-// output column l & 31), 16 accumulator registers per 32 output columns
-// (column l & 31, row (r & 3) + 8 (r >> 2) + 4 (l >> 5)).  The instruction is
-// an exact k-ordered fp32 fmaf chain, so results do not depend on the tiling.
+// MLP chain.  A wave owns 32 rows and keeps their activations in registers
+// from the first load to the final store; LDS only holds the weights, shared
+// by the workgroup.  Every layer is computed transposed, Y^T = W X^T, with
+// v_mfma_f32_32x32x2_f32: the A operand is a weight (lane l: output channel
+// l & 31 of the block, k-half l >> 5, read from LDS), the B operand is an
+// activation of the lane's own row (row l & 31), and the 16 accumulators of a
+// lane are 16 output channels of that same row (channel (r & 3) + 8 (r >> 2)
+// + 4 (l >> 5) of the block).  An accumulator is therefore directly the B
+// operand of the next layer: the order in which the input channels are summed
+// is chosen to match what each lane already holds, so no transposition and no
+// LDS round trip happens between layers.  For the first layer a lane reads a
+// contiguous half of its row's chunk (k-half 0: first half of the columns,
+// k-half 1: second half).  The instruction is an exact fp32 fmaf chain; only
+// the summation order differs from a sequential dot product.
 // BatchNorm (eval) and the bias collapse into one scale and one shift per
-// output column, applied with the activation in the epilogue.
+// output channel, applied with the activation on the accumulators.
 //
 // Limits of one launch: every layer's output width <= 64 and every layer
 // after the first has input width <= 64; the first layer's input is streamed
@@ -28,7 +34,6 @@ constexpr int MLP_THREADS = 256;
 constexpr int MLP_WAVES = 4;
 constexpr int MLP_ROWS = 32 * MLP_WAVES;   // rows per workgroup step
 constexpr int MLP_KC = 64;                 // input columns per chunk
-constexpr int MLP_PITCH = 66;              // floats per tile row: lanes (row, k) hit distinct banks
 constexpr int MLP_MAX_LAYERS = 3;
 constexpr int MLP_MAX_C = 64;
 
@@ -42,20 +47,19 @@ struct MlpArgs {
     MlpSrc a, b;          // input row = [a | b] (mode 0), a + b (mode 1), [a | a + b] (mode 2)
     int mode;
     int nlayers;
+    int vec_in, vec_out;  // 16-byte loads / stores are possible
     i64 rows;
     mvf_mlp_layer L[MLP_MAX_LAYERS];
     float *out;
     int ldo;
 };
 
-__device__ __forceinline__ int pad2(int v) { return (v + 1) & ~1; }
-__device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
-
-// Orders LDS traffic between the lanes of one wave (tile writes before reads).
-__device__ __forceinline__ void wave_sync()
+__host__ __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
+// LDS rows of a layer's transposed weights
+__host__ __device__ __forceinline__ int mlp_wrows(int layer, int cin)
 {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if (layer == 0) return cin < MLP_KC ? ((cin + 7) & ~7) : MLP_KC;   // whole groups of 4 steps per k-half
+    return pad32(cin);
 }
 
 __device__ __forceinline__ float mlp_input(const MlpArgs &A, i64 ra, i64 rb, int c)
@@ -68,71 +72,146 @@ __device__ __forceinline__ float mlp_input(const MlpArgs &A, i64 ra, i64 rb, int
     return A.b.p[rb * A.b.ld + c];
 }
 
-// One layer's K loop over kc2 / 2 steps: acc += tile[32 x kc2] * wt[kc2 x cop].
-__device__ __forceinline__ void mlp_mma(
-    const float *tile, const float *wt, int kc2, int cop, int lane, floatx16 &acc0, floatx16 &acc1)
+__device__ __forceinline__ float4 ld4(const float *p) { return *(const float4 *)p; }
+__device__ __forceinline__ float4 add4(const float4 &x, const float4 &y)
 {
-    const int i = lane & 31, kh = lane >> 5;
-    const float *ta = tile + i * MLP_PITCH + kh;
-    const float *wb = wt + kh * cop + i;
-    if (cop > 32) {
-        for (int k = 0; k < kc2; k += 2) {
-            const float a = ta[k];
-            const float b0 = wb[k * cop], b1 = wb[k * cop + 32];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    return make_float4(__fadd_rn(x.x, y.x), __fadd_rn(x.y, y.y), __fadd_rn(x.z, y.z), __fadd_rn(x.w, y.w));
+}
+
+// The lane's S (a multiple of 4, at most 32) input columns c0 .. c0 + S of its
+// row as eight 16-byte loads without any branch: columns beyond S are read
+// from c0 again and never used.  pa / pb point at the lane's row in the two
+// sources (pb = pa when there is one source); ca = columns of the first one.
+template <int MODE>
+__device__ __forceinline__ void mlp_load_row(
+    const float *pa, const float *pb, int ca, int c0, int S, float (&xr)[32])
+{
+    float4 u[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = c0 + (4 * q < S ? 4 * q : 0);
+        if (MODE == 0) {
+            u[q] = ld4(c < ca ? pa + c : pb + (c - ca));
+        } else if (MODE == 1) {
+            u[q] = ld4(pa + c);
+            w[q] = ld4(pb + c);
+        } else {
+            const int cc = c < ca ? c : c - ca;
+            u[q] = ld4(pa + cc);
+            w[q] = ld4(pb + cc);
         }
-    } else {
-        for (int k = 0; k < kc2; k += 2) {
-            const float a = ta[k];
-            const float b0 = wb[k * cop];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float4 v = u[q];
+        if (MODE == 1) v = add4(u[q], w[q]);
+        if (MODE == 2) {
+            const int c = c0 + (4 * q < S ? 4 * q : 0);
+            if (c >= ca) v = add4(u[q], w[q]);
         }
+        xr[4 * q] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
     }
 }
 
-// Scale, shift, activation; to the wave's tile (next layer's input) or to out.
+// Channel of accumulator register r inside its block of 32, for k-half kh.
+__device__ __forceinline__ int acc_channel(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// Scale, shift, activation on the accumulators of output block nb.
 __device__ __forceinline__ void mlp_epilogue(
-    const floatx16 &acc, int col0, const float *sc, const float *sh, const mvf_mlp_layer &L,
-    float *tile, float *out, int ldo, i64 row0, i64 rows, int lane)
+    floatx16 &acc, int nb, const float *sc, const float *sh, const mvf_mlp_layer &L, int kh)
 {
-    const int j = col0 + (lane & 31), kh = lane >> 5;
-    const float s = sc[j], t = sh[j];
+    const float *s = sc + nb * 32 + 4 * kh, *t = sh + nb * 32 + 4 * kh;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        float v = __fadd_rn(__fmul_rn(acc[r], s), t);
+        const int ch = (r & 3) + 8 * (r >> 2);
+        float v = __fadd_rn(__fmul_rn(acc[r], s[ch]), t[ch]);
         if (L.act) v = v > 0.f ? v : __fmul_rn(v, L.slope);
-        if (out) {
-            if (row0 + row < rows && j < L.cout) out[(row0 + row) * ldo + j] = v;
-        } else {
-            tile[row * MLP_PITCH + j] = v;
+        acc[r] = v;
+    }
+}
+
+// n += W[:, 32-channel block held in acc] * acc, 16 steps in groups of 4.
+__device__ __forceinline__ void mlp_next_layer(
+    const floatx16 &acc, const float *wp, int cop2, floatx16 &n0, floatx16 &n1)
+{
+    if (cop2 > 32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float w0[4], w1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { w0[e] = wp[(8 * g + e) * cop2]; w1[e] = wp[(8 * g + e) * cop2 + 32]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], acc[4 * g + e], n0, 0, 0, 0);
+                n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], acc[4 * g + e], n1, 0, 0, 0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float w0[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w0[e] = wp[(8 * g + e) * cop2];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], acc[4 * g + e], n0, 0, 0, 0);
         }
     }
 }
 
+__device__ __forceinline__ void mlp_store(
+    const floatx16 &acc, int nb, const MlpArgs &A, bool vec_out, int cout, i64 row, int kh)
+{
+    float *o = A.out + row * A.ldo + nb * 32 + 4 * kh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = nb * 32 + 4 * kh + 8 * g;
+        if (vec_out) {
+            if (c < cout) *(float4 *)(o + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < cout) o[8 * g + e] = acc[4 * g + e];
+        }
+    }
+}
+
+// NL / WMASK >= 0 fix the number of layers and which of them are wider than 32
+// outputs (bit l of WMASK) at compile time, for the aligned single-source or
+// concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
+// and LDS offsets become immediates.  NL < 0 is the general kernel that takes
+// everything from the arguments.
+template <int NL, int WMASK>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 {
+    constexpr bool FIXED = NL >= 0;
+    const int nlayers = FIXED ? NL : A.nlayers;
+    const int mode = FIXED ? 0 : A.mode;
+    const bool vec_in = FIXED ? true : A.vec_in != 0;
+    const bool vec_out = FIXED ? true : A.vec_out != 0;
+    // padded output width of layer l
+    auto cop_of = [&](int l) { return FIXED ? (((WMASK >> l) & 1) ? 64 : 32) : pad32(A.L[l].cout); };
     extern __shared__ float smem[];
-    float *sc = smem;                                   // [3][64] column scales
-    float *sh = sc + MLP_MAX_LAYERS * MLP_MAX_C;        // [3][64] column shifts
-    float *tiles = sh + MLP_MAX_LAYERS * MLP_MAX_C;     // one 32-row tile per wave
-    float *wt[MLP_MAX_LAYERS];                          // transposed weights [k][cout_pad]
+    float *sc = smem;                                   // [3][64] channel scales
+    float *sh = sc + MLP_MAX_LAYERS * MLP_MAX_C;        // [3][64] channel shifts
+    // transposed weights [k][cout_pad] of the layers, as offsets into smem (plain
+    // offsets keep the accesses LDS instructions)
+    int woff[MLP_MAX_LAYERS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    float *tile = tiles + wave * 32 * MLP_PITCH;
+    const int jrow = lane & 31, kh = lane >> 5;
 
     const int cin0 = A.L[0].cin;
     const int nchunks = (cin0 + MLP_KC - 1) / MLP_KC;
     {
-        float *w = tiles + MLP_WAVES * 32 * MLP_PITCH;
-        for (int l = 0; l < A.nlayers; ++l) {
-            wt[l] = w;
-            const int kin = l == 0 ? (cin0 < MLP_KC ? pad2(cin0) : MLP_KC) : pad2(A.L[l].cin);
-            w += kin * pad32(A.L[l].cout);
+        int w = 2 * MLP_MAX_LAYERS * MLP_MAX_C;
+#pragma unroll
+        for (int l = 0; l < MLP_MAX_LAYERS; ++l) {
+            woff[l] = w;
+            if (l < nlayers) w += mlp_wrows(l, A.L[l].cin) * cop_of(l);
         }
     }
-    // column scale / shift: y = (x W^T + bias - mean) / sqrt(var + eps) * gamma + beta
-    for (int idx = tid; idx < A.nlayers * MLP_MAX_C; idx += MLP_THREADS) {
+    // channel scale / shift: y = (x W^T + bias - mean) / sqrt(var + eps) * gamma + beta
+    for (int idx = tid; idx < nlayers * MLP_MAX_C; idx += MLP_THREADS) {
         const int l = idx / MLP_MAX_C, j = idx - l * MLP_MAX_C;
         const mvf_mlp_layer &L = A.L[l];
         float s = 0.f, t = 0.f;
@@ -147,70 +226,132 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         sc[idx] = s;
         sh[idx] = t;
     }
-    // resident weights: every layer but a chunked first one
-    for (int l = (nchunks > 1 ? 1 : 0); l < A.nlayers; ++l) {
+    // resident weights: every layer but a chunked first one; rows and columns
+    // beyond the layer are zero
+    for (int l = (nchunks > 1 ? 1 : 0); l < nlayers; ++l) {
         const mvf_mlp_layer &L = A.L[l];
-        const int kin = pad2(L.cin), cop = pad32(L.cout);
+        const int kin = mlp_wrows(l, L.cin), cop = cop_of(l);
         for (int idx = tid; idx < kin * cop; idx += MLP_THREADS) {
             const int k = idx / cop, j = idx - k * cop;
-            wt[l][idx] = (k < L.cin && j < L.cout) ? L.weight[(size_t)j * L.cin + k] : 0.f;
+            smem[(l == 0 ? woff[0] : l == 1 ? woff[1] : woff[2]) + idx] =
+                (k < L.cin && j < L.cout) ? L.weight[(size_t)j * L.cin + k] : 0.f;
         }
     }
     __syncthreads();
 
-    const bool gather_a = A.a.gather != nullptr, gather_b = A.b.gather != nullptr;
-    for (i64 base = (i64)blockIdx.x * MLP_ROWS; base < A.rows; base += (i64)gridDim.x * MLP_ROWS) {
-        const i64 row0 = base + wave * 32;
+    const int cop0 = cop_of(0);
+    float xr[32];
+    // The lane's half of a 64-column chunk of its row, 16-byte loads.  Rows past
+    // the end read row 0; their results are never stored.
+    auto load_rows = [&](i64 base_, int k0, int S) {
+        const i64 row_ = base_ + wave * 32 + jrow;
+        const bool live_ = row_ < A.rows;
+        i64 ra = live_ ? row_ : 0, rb = ra;
+        if (live_ && A.a.gather) ra = A.a.gather[row_];
+        if (live_ && A.b.gather) rb = A.b.gather[row_];
+        const float *pa = A.a.p + ra * A.a.ld;
+        const float *pb = A.b.p ? A.b.p + rb * A.b.ld : pa;
+        if (mode == 0) mlp_load_row<0>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
+        else if (mode == 1) mlp_load_row<1>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
+        else mlp_load_row<2>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
+    };
+    // With a single chunk the next tile's rows are requested right after the
+    // first layer has consumed the current ones, so their latency hides behind
+    // the remaining layers.
+    const bool prefetch = vec_in && nchunks == 1;
+    const i64 stride = (i64)gridDim.x * MLP_ROWS;
+    if (prefetch && (i64)blockIdx.x * MLP_ROWS < A.rows) load_rows((i64)blockIdx.x * MLP_ROWS, 0, (cin0 + 1) >> 1);
+    for (i64 base = (i64)blockIdx.x * MLP_ROWS; base < A.rows; base += stride) {
+        const i64 row = base + wave * 32 + jrow;
+        const bool live = row < A.rows;
         floatx16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-        // ---- first layer, input streamed in chunks of 64 columns ----
+        // ---- first layer: the lane's half of each 64-column chunk of its row ----
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int k0 = chunk * MLP_KC;
             const int kc = cin0 - k0 < MLP_KC ? cin0 - k0 : MLP_KC;
-            const int kc2 = pad2(kc), cop = pad32(A.L[0].cout);
+            const int S = (kc + 1) >> 1;                 // MFMA steps of the chunk
             if (nchunks > 1) {
-                __syncthreads();                      // every wave is done with the previous chunk
+                __syncthreads();                         // every wave is done with the previous chunk
                 const mvf_mlp_layer &L = A.L[0];
-                for (int idx = tid; idx < kc2 * cop; idx += MLP_THREADS) {
-                    const int k = idx / cop, j = idx - k * cop;
-                    wt[0][idx] = (k < kc && j < L.cout) ? L.weight[(size_t)j * L.cin + k0 + k] : 0.f;
+                for (int idx = tid; idx < MLP_KC * cop0; idx += MLP_THREADS) {
+                    const int k = idx / cop0, j = idx - k * cop0;
+                    smem[woff[0] + idx] = (k < kc && j < L.cout) ? L.weight[(size_t)j * L.cin + k0 + k] : 0.f;
                 }
             }
-            // the wave's 32 x 64 input tile, one row per step, zero beyond the data
-#pragma unroll 4
-            for (int r = 0; r < 32; ++r) {
-                const i64 row = row0 + r;
-                float v = 0.f;
-                if (row < A.rows && lane < kc) {
-                    const i64 ra = gather_a ? (i64)A.a.gather[row] : row;
-                    const i64 rb = gather_b ? (i64)A.b.gather[row] : row;
-                    v = mlp_input(A, ra, rb, k0 + lane);
-                }
-                tile[r * MLP_PITCH + lane] = v;
-            }
-            if (nchunks > 1) __syncthreads(); else wave_sync();
-            mlp_mma(tile, wt[0], kc2, cop, lane, acc0, acc1);
-            wave_sync();
-        }
-        // ---- epilogues and the following layers ----
-        for (int l = 0; l < A.nlayers; ++l) {
-            const mvf_mlp_layer &L = A.L[l];
-            const bool last = l == A.nlayers - 1;
-            float *o = last ? A.out : nullptr;
-            const int cop = pad32(L.cout);
-            mlp_epilogue(acc0, 0, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, tile, o, A.ldo, row0, A.rows, lane);
-            if (cop > 32)
-                mlp_epilogue(acc1, 32, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, tile, o, A.ldo, row0, A.rows, lane);
-            if (last) break;
-            // the tile's pad column feeds the next layer's odd k: keep it finite
-            if ((L.cout & 1) && lane < 32) tile[lane * MLP_PITCH + L.cout] = 0.f;
-            wave_sync();
+            const int c_lo = kh * S;                     // first column of this lane inside the chunk
+            if (!prefetch) {
+                if (vec_in) {
+                    load_rows(base, k0, S);
+                } else {
+                    i64 ra = row, rb = row;
+                    if (live && A.a.gather) ra = A.a.gather[row];
+                    if (live && A.b.gather) rb = A.b.gather[row];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            mlp_mma(tile, wt[l + 1], pad2(A.L[l + 1].cin), pad32(A.L[l + 1].cout), lane, acc0, acc1);
-            wave_sync();
+                    for (int t = 0; t < 32; ++t) {
+                        xr[t] = 0.f;
+                        if (live && t < S && c_lo + t < kc) xr[t] = mlp_input(A, ra, rb, k0 + c_lo + t);
+                    }
+                }
+            }
+            if (nchunks > 1) __syncthreads();
+            // groups of 4 steps: the weights of a group are read together; steps
+            // beyond S meet zero activations (scalar path) or are whole groups
+            const float *wp = smem + woff[0] + c_lo * cop0 + jrow;
+            if (cop0 > 32) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (4 * g < S) {
+                        float w0[4], w1[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { w0[e] = wp[(4 * g + e) * cop0]; w1[e] = wp[(4 * g + e) * cop0 + 32]; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], xr[4 * g + e], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], xr[4 * g + e], acc1, 0, 0, 0);
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (4 * g < S) {
+                        float w0[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w0[e] = wp[(4 * g + e) * cop0];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], xr[4 * g + e], acc0, 0, 0, 0);
+                    }
+            }
+            if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
+        }
+        // ---- epilogues and the following layers, activations stay in registers ----
+#pragma unroll
+        for (int l = 0; l < (FIXED ? NL : MLP_MAX_LAYERS); ++l) {
+            if (l >= nlayers) break;
+            const mvf_mlp_layer &L = A.L[l];
+            const int cop = cop_of(l);
+            mlp_epilogue(acc0, 0, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, kh);
+            if (cop > 32) mlp_epilogue(acc1, 1, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, kh);
+            if (l == nlayers - 1) {
+                if (live) {
+                    mlp_store(acc0, 0, A, vec_out, L.cout, row, kh);
+                    if (cop > 32) mlp_store(acc1, 1, A, vec_out, L.cout, row, kh);
+                }
+                break;
+            }
+            const int cop2 = cop_of(l + 1);
+            // the lane's register r of block nb is input channel nb * 32 + acc_channel(r, kh)
+            const float *wp = smem + (l == 0 ? woff[1] : woff[2]) + (4 * kh) * cop2 + jrow;
+            floatx16 n0, n1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
+            mlp_next_layer(acc0, wp, cop2, n0, n1);
+            if (cop > 32) mlp_next_layer(acc1, wp + 32 * cop2, cop2, n0, n1);
+            acc0 = n0;
+            acc1 = n1;
         }
     }
 }
@@ -218,16 +359,52 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 // ------------------------------------------------------------------------- //
 // attention scores inside CSR segments                                       //
 // ------------------------------------------------------------------------- //
-// One thread per (segment, group).  comp[r][g] = sum_k K[r][g D + k] Q[s][g D + k]
-// (products and sums rounded one by one, k ascending; optionally / sqrt(D)), or
-// comp is given.  att = segment softmax of comp (max-centred, optional
-// / sqrt(rows), eps in the denominator; pooling.py:770-822), gate[s][g] =
-// tanh(relu(max_r comp * Gw[g] + Gb[g])) (pooling.py:717-723, 523-526).
-__global__ __launch_bounds__(256) void attention_scores_kernel(
+// comp[r][g] = sum_k K[r][g D + k] * Q[s(r)][g D + k], products and sums rounded
+// one by one, k ascending (the reference's elementwise product followed by
+// sum(dim=2), pooling.py:504-508), optionally / sqrt(D).  One thread per
+// (row, group): neighbouring threads read neighbouring keys.
+__global__ __launch_bounds__(256) void attention_comp_kernel(
     const float *__restrict__ keys, int ldk, const float *__restrict__ queries, int ldq,
-    int q_per_row, const i64 *__restrict__ ptr, i64 nseg, int G, int D, float dim_div, int group_scaling,
+    const int *__restrict__ row2seg, i64 rows, int G, int D, float dim_div,
+    float *__restrict__ comp)
+{
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= rows * G) return;
+    const i64 r = t / G;
+    const int g = (int)(t - r * G);
+    const i64 qr = row2seg ? (i64)row2seg[r] : r;
+    const float *k = keys + (size_t)r * ldk + (size_t)g * D;
+    const float *q = queries + (size_t)qr * ldq + (size_t)g * D;
+    float c;
+    if ((D & 3) == 0 && (ldk & 3) == 0 && (ldq & 3) == 0 &&
+        ((uintptr_t)keys & 15) == 0 && ((uintptr_t)queries & 15) == 0) {
+        float4 kv = *(const float4 *)k, qv = *(const float4 *)q;
+        c = __fmul_rn(kv.x, qv.x);
+        c = __fadd_rn(c, __fmul_rn(kv.y, qv.y));
+        c = __fadd_rn(c, __fmul_rn(kv.z, qv.z));
+        c = __fadd_rn(c, __fmul_rn(kv.w, qv.w));
+        for (int d = 4; d < D; d += 4) {
+            kv = *(const float4 *)(k + d); qv = *(const float4 *)(q + d);
+            c = __fadd_rn(c, __fmul_rn(kv.x, qv.x));
+            c = __fadd_rn(c, __fmul_rn(kv.y, qv.y));
+            c = __fadd_rn(c, __fmul_rn(kv.z, qv.z));
+            c = __fadd_rn(c, __fmul_rn(kv.w, qv.w));
+        }
+    } else {
+        c = __fmul_rn(k[0], q[0]);
+        for (int d = 1; d < D; ++d) c = __fadd_rn(c, __fmul_rn(k[d], q[d]));
+    }
+    if (dim_div != 0.f) c = __fdiv_rn(c, dim_div);
+    comp[t] = c;
+}
+
+// One thread per (segment, group): att = segment softmax of comp (max-centred,
+// optional / sqrt(rows), eps in the denominator; pooling.py:770-822), gate[s][g]
+// = tanh(relu(max_r comp * Gw[g] + Gb[g])) (pooling.py:717-723, 523-526).
+__global__ __launch_bounds__(256) void attention_scores_kernel(
+    const i64 *__restrict__ ptr, i64 nseg, int G, int group_scaling,
     float eps, const float *__restrict__ gate_w, const float *__restrict__ gate_b,
-    float *__restrict__ comp, float *__restrict__ att, float *__restrict__ gate)
+    const float *__restrict__ comp, float *__restrict__ att, float *__restrict__ gate)
 {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= nseg * G) return;
@@ -235,21 +412,9 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
     const int g = (int)(t - s * G);
     const i64 a = ptr[s], b = ptr[s + 1];
     float mx = 0.f;                                    // segment max of nothing is 0
-    if (keys) {
-        for (i64 r = a; r < b; ++r) {
-            const float *q = queries + (size_t)(q_per_row ? r : s) * ldq + (size_t)g * D;
-            const float *k = keys + (size_t)r * ldk + (size_t)g * D;
-            float c = __fmul_rn(k[0], q[0]);
-            for (int d = 1; d < D; ++d) c = __fadd_rn(c, __fmul_rn(k[d], q[d]));
-            if (dim_div != 0.f) c = __fdiv_rn(c, dim_div);
-            comp[(size_t)r * G + g] = c;
-            mx = (r == a || c > mx) ? c : mx;
-        }
-    } else {
-        for (i64 r = a; r < b; ++r) {
-            const float c = comp[(size_t)r * G + g];
-            mx = (r == a || c > mx) ? c : mx;
-        }
+    for (i64 r = a; r < b; ++r) {
+        const float c = comp[(size_t)r * G + g];
+        mx = (r == a || c > mx) ? c : mx;
     }
     if (gate) {
         float x = mx;
@@ -272,26 +437,86 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
 }
 
 // x_pool[s][c] = (sum_r x[r][c] * att[r][group(c)]) * gate[s][group(c)], rows
-// in order, one (segment, channel) pair per thread step as in segment_csr.
+// in order.  The output is walked flat in vectors of VEC channels (VEC = 4
+// needs every vector inside one group), four (segment, vector) pairs in flight
+// per thread and four rows per step, as in segment_csr.
+constexpr int ATT_ILP = 4;
+
+template <int VEC> struct AttVec;
+template <> struct AttVec<1> {
+    typedef float T;
+    static __device__ __forceinline__ float mul(float x, float w) { return __fmul_rn(x, w); }
+    static __device__ __forceinline__ float fma_(float acc, float x, float w) { return __fadd_rn(acc, __fmul_rn(x, w)); }
+    static __device__ __forceinline__ float zero() { return 0.f; }
+};
+template <> struct AttVec<4> {
+    typedef float4 T;
+    static __device__ __forceinline__ float4 mul(const float4 &x, float w)
+    {
+        return make_float4(__fmul_rn(x.x, w), __fmul_rn(x.y, w), __fmul_rn(x.z, w), __fmul_rn(x.w, w));
+    }
+    static __device__ __forceinline__ float4 fma_(const float4 &a, const float4 &x, float w)
+    {
+        return make_float4(__fadd_rn(a.x, __fmul_rn(x.x, w)), __fadd_rn(a.y, __fmul_rn(x.y, w)),
+                           __fadd_rn(a.z, __fmul_rn(x.z, w)), __fadd_rn(a.w, __fmul_rn(x.w, w)));
+    }
+    static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+
+template <int VEC>
 __global__ __launch_bounds__(256) void attention_pool_kernel(
     const float *__restrict__ x, int C, const float *__restrict__ att, int G,
     const int *__restrict__ chan2group, const float *__restrict__ gate,
     const i64 *__restrict__ ptr, i64 nseg, float *__restrict__ out)
 {
-    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (e >= nseg * C) return;
-    const i64 s = e / C;
-    const int c = (int)(e - s * C);
-    const int g = chan2group ? chan2group[c] : 0;
-    const i64 a = ptr[s], b = ptr[s + 1];
-    float acc = 0.f;
-    if (b > a) {
-        acc = __fmul_rn(x[(size_t)a * C + c], att[(size_t)a * G + g]);
-        for (i64 r = a + 1; r < b; ++r)
-            acc = __fadd_rn(acc, __fmul_rn(x[(size_t)r * C + c], att[(size_t)r * G + g]));
+    typedef AttVec<VEC> AV;
+    typedef typename AV::T V;
+    const unsigned cv = (unsigned)(C / VEC);
+    const i64 total = nseg * cv;
+    const V *xs = (const V *)x;
+    V *o = (V *)out;
+    const i64 e0 = (i64)blockIdx.x * (256 * ATT_ILP) + threadIdx.x;
+    const i64 seg0 = ((i64)blockIdx.x * (256 * ATT_ILP)) / cv;
+    const unsigned rem0 = (unsigned)((i64)blockIdx.x * (256 * ATT_ILP) - seg0 * cv) + threadIdx.x;
+    i64 a[ATT_ILP], b[ATT_ILP], s[ATT_ILP];
+    unsigned c[ATT_ILP];
+    int g[ATT_ILP];
+    V acc[ATT_ILP];
+#pragma unroll
+    for (int k = 0; k < ATT_ILP; ++k) {
+        a[k] = b[k] = s[k] = 0; c[k] = 0; g[k] = 0;
+        if (e0 + k * 256 < total) {
+            const unsigned off = rem0 + k * 256, ds = off / cv;
+            s[k] = seg0 + ds;
+            c[k] = off - ds * cv;
+            g[k] = chan2group ? chan2group[c[k] * VEC] : 0;
+            a[k] = ptr[s[k]];
+            b[k] = ptr[s[k] + 1];
+        }
     }
-    if (gate) acc = __fmul_rn(acc, gate[(size_t)s * G + g]);
-    out[e] = acc;
+#pragma unroll
+    for (int k = 0; k < ATT_ILP; ++k) {
+        acc[k] = AV::zero();
+        if (b[k] > a[k]) acc[k] = AV::mul(xs[(size_t)a[k] * cv + c[k]], att[(size_t)a[k] * G + g[k]]);
+    }
+#pragma unroll
+    for (int k = 0; k < ATT_ILP; ++k) {
+        i64 r = a[k] + 1;
+        for (; r + 4 <= b[k]; r += 4) {
+            const V *q = xs + (size_t)r * cv + c[k];
+            const float *w = att + (size_t)r * G + g[k];
+            const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
+            const float w0 = w[0], w1 = w[G], w2 = w[2 * G], w3 = w[3 * G];
+            acc[k] = AV::fma_(acc[k], x0, w0); acc[k] = AV::fma_(acc[k], x1, w1);
+            acc[k] = AV::fma_(acc[k], x2, w2); acc[k] = AV::fma_(acc[k], x3, w3);
+        }
+        for (; r < b[k]; ++r)
+            acc[k] = AV::fma_(acc[k], xs[(size_t)r * cv + c[k]], att[(size_t)r * G + g[k]]);
+        if (e0 + k * 256 < total) {
+            if (gate) acc[k] = AV::mul(acc[k], gate[(size_t)s[k] * G + g[k]]);
+            o[e0 + k * 256] = acc[k];
+        }
+    }
 }
 
 // row -> segment index of a CSR pointer array.
@@ -331,11 +556,8 @@ __global__ __launch_bounds__(256) void segment_pick_kernel(
 
 static size_t mlp_lds_bytes(const mvf_mlp_layer *L, int n)
 {
-    size_t f = 2 * MLP_MAX_LAYERS * MLP_MAX_C + (size_t)MLP_WAVES * 32 * MLP_PITCH;
-    for (int l = 0; l < n; ++l) {
-        const int kin = l == 0 ? (L[l].cin < MLP_KC ? ((L[l].cin + 1) & ~1) : MLP_KC) : ((L[l].cin + 1) & ~1);
-        f += (size_t)kin * ((L[l].cout + 31) & ~31);
-    }
+    size_t f = 2 * MLP_MAX_LAYERS * MLP_MAX_C;
+    for (int l = 0; l < n; ++l) f += (size_t)mlp_wrows(l, L[l].cin) * pad32(L[l].cout);
     return f * sizeof(float);
 }
 
@@ -379,6 +601,11 @@ extern "C" int mvf_mlp_forward(
     for (int l = 0; l < nlayers; ++l) A.L[l] = layers[l];
     A.out = out;
     A.ldo = ldo;
+    // 16-byte access: every chunk splits into halves of whole float4s that stay inside one source
+    const bool al_a = ((uintptr_t)xa % 16 == 0) && lda % 4 == 0;
+    const bool al_b = !xb || (((uintptr_t)xb % 16 == 0) && ldb % 4 == 0);
+    A.vec_in = al_a && al_b && cin0 % 8 == 0 && cols_a % 4 == 0;
+    A.vec_out = ((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0;
     const size_t lds = mlp_lds_bytes(layers, nlayers);
     static int cus = 0;
     if (cus == 0) {
@@ -388,19 +615,45 @@ extern "C" int mvf_mlp_forward(
             cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    const i64 want = (rows + MLP_ROWS - 1) / MLP_ROWS, cap = (i64)cus * 2;
+    const i64 per_cu = (i64)(160 * 1024 / (lds + 1024));
+    const i64 want = (rows + MLP_ROWS - 1) / MLP_ROWS, cap = (i64)cus * (per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu);
     dim3 grid((unsigned)(want < cap ? want : cap));
-    MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    hipLaunchKernelGGL(mlp_chain_kernel, grid, dim3(MLP_THREADS), lds, (hipStream_t)stream, A);
+    int wmask = 0;
+    for (int l = 0; l < nlayers; ++l) wmask |= (layers[l].cout > 32 ? 1 : 0) << l;
+    const bool fixed = A.vec_in && A.vec_out && mode == 0;
+    hipStream_t st = (hipStream_t)stream;
+#define MVF_MLP_LAUNCH(NL_, WM_)                                                                 \
+    do {                                                                                         \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_>,                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_>), grid, dim3(MLP_THREADS), lds, st, A);   \
+    } while (0)
+    if (!fixed) MVF_MLP_LAUNCH(-1, 0);
+    else switch (nlayers * 8 + wmask) {
+    case 8 + 0: MVF_MLP_LAUNCH(1, 0); break;
+    case 8 + 1: MVF_MLP_LAUNCH(1, 1); break;
+    case 16 + 0: MVF_MLP_LAUNCH(2, 0); break;
+    case 16 + 1: MVF_MLP_LAUNCH(2, 1); break;
+    case 16 + 2: MVF_MLP_LAUNCH(2, 2); break;
+    case 16 + 3: MVF_MLP_LAUNCH(2, 3); break;
+    case 24 + 0: MVF_MLP_LAUNCH(3, 0); break;
+    case 24 + 1: MVF_MLP_LAUNCH(3, 1); break;
+    case 24 + 2: MVF_MLP_LAUNCH(3, 2); break;
+    case 24 + 3: MVF_MLP_LAUNCH(3, 3); break;
+    case 24 + 4: MVF_MLP_LAUNCH(3, 4); break;
+    case 24 + 5: MVF_MLP_LAUNCH(3, 5); break;
+    case 24 + 6: MVF_MLP_LAUNCH(3, 6); break;
+    default: MVF_MLP_LAUNCH(3, 7); break;
+    }
+#undef MVF_MLP_LAUNCH
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
 
 extern "C" int mvf_attention_pool(
-    const float *keys, int32_t ldk, const float *queries, int32_t ldq, int32_t q_per_row,
-    const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,
-    int32_t dim_scaling, int32_t group_scaling, float eps, const int32_t *chan2group,
+    const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
+    const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G,
+    int32_t D, int32_t dim_scaling, int32_t group_scaling, float eps, const int32_t *chan2group,
     const float *gate_w, const float *gate_b, int32_t gating,
     float *comp, float *att, float *gate, float *out, void *stream)
 {
@@ -412,13 +665,25 @@ extern "C" int mvf_attention_pool(
     if (nseg == 0) return MVF_OK;
     MVF_REQUIRE(ptr && out && (rows == 0 || (x_mod && comp && att)), "attention_pool: null buffer");
     hipStream_t st = (hipStream_t)stream;
-    const float dim_div = (keys && dim_scaling) ? (float)sqrt((double)D) : 0.f;
+    if (keys && rows > 0) {
+        const float dim_div = dim_scaling ? (float)sqrt((double)D) : 0.f;
+        hipLaunchKernelGGL(attention_comp_kernel, dim3(cdiv(rows * G, 256)), dim3(256), 0, st,
+                           keys, ldk, queries, ldq, row2seg, (i64)rows, G, D, dim_div, comp);
+    }
     hipLaunchKernelGGL(attention_scores_kernel, dim3(cdiv(nseg * G, 256)), dim3(256), 0, st,
-                       keys, ldk, queries, ldq, q_per_row, (const i64 *)ptr, (i64)nseg, G, D, dim_div,
-                       group_scaling, eps, gate_w, gate_b, comp, att, gating ? gate : (float *)nullptr);
-    hipLaunchKernelGGL(attention_pool_kernel, dim3(cdiv(nseg * C, 256)), dim3(256), 0, st,
-                       x_mod, C, att, G, G == 1 ? (const int *)nullptr : chan2group,
-                       gating ? gate : (const float *)nullptr, (const i64 *)ptr, (i64)nseg, out);
+                       (const i64 *)ptr, (i64)nseg, G, group_scaling, eps, gate_w, gate_b,
+                       (const float *)comp, att, gating ? gate : (float *)nullptr);
+    // 16-byte vectors when no vector of 4 channels straddles two groups
+    const bool vec4 = C % 4 == 0 && ((uintptr_t)x_mod % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                      (G == 1 || (C % G == 0 && (C / G) % 4 == 0));
+    if (vec4)
+        hipLaunchKernelGGL((attention_pool_kernel<4>), dim3(cdiv(nseg * (C / 4), 256 * ATT_ILP)), dim3(256), 0, st,
+                           x_mod, C, att, G, G == 1 ? (const int *)nullptr : chan2group,
+                           gating ? gate : (const float *)nullptr, (const i64 *)ptr, (i64)nseg, out);
+    else
+        hipLaunchKernelGGL((attention_pool_kernel<1>), dim3(cdiv(nseg * C, 256 * ATT_ILP)), dim3(256), 0, st,
+                           x_mod, C, att, G, G == 1 ? (const int *)nullptr : chan2group,
+                           gating ? gate : (const float *)nullptr, (const i64 *)ptr, (i64)nseg, out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

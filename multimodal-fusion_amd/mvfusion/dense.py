@@ -182,10 +182,11 @@ def csr_row_segments(ptr, rows):
 
 
 def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
-                   q_per_row=False, comp=None, nc_qk=1, dim_scaling=False,
+                   row2seg=None, comp=None, nc_qk=1, dim_scaling=False,
                    group_scaling=False, gate_w=None, gate_b=None, gating=False, eps=1e-12):
     """Returns (x_pool, comp, att, gate).  Either ``keys``/``queries`` or
-    ``comp`` (the compatibilities) is given."""
+    ``comp`` (the compatibilities) is given; ``row2seg`` maps key rows to query
+    rows (None: one query row per key row)."""
     lib = L.load()
     dev = x_mod.device
     rows, Cm = x_mod.shape
@@ -205,7 +206,7 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
         with torch.cuda.device(dev):
             L.check(lib.mvf_attention_pool(
                 L.ptr(keys), 0 if keys is None else keys.stride(0),
-                L.ptr(queries), 0 if queries is None else queries.stride(0), int(q_per_row),
+                L.ptr(queries), 0 if queries is None else queries.stride(0), L.ptr(row2seg),
                 L.ptr(x_mod), Cm, L.ptr(ptr), nseg, rows, G, int(nc_qk),
                 int(bool(dim_scaling)), int(bool(group_scaling)), float(eps),
                 L.ptr(chan2group), L.ptr(gw), L.ptr(gb), int(bool(gating)),

@@ -573,7 +573,7 @@ class QKVBimodalCSRPool(_AttentivePool):
 
         x_pool, comp, att, gate = _dense.attention_pool(
             x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), keys=keys,
-            queries=queries, q_per_row=self.use_mod_q, nc_qk=self.nc_qk,
+            queries=queries, row2seg=None if self.use_mod_q else row2seg, nc_qk=self.nc_qk,
             dim_scaling=self.dim_scaling, group_scaling=self.group_scaling,
             gate_w=None if self.G is None else self.G.weight,
             gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)

@@ -45,10 +45,11 @@ def test_qkv_pool_golden(golden, name):
     _close(mod._last_A, g["A"], rtol=1e-4)
     if bool(g["gating"]):
         _close(mod._last_G, g["G"], rtol=1e-4)
-    # the fused path (no save_last: K behind the map encoder) gives the same result
+    # the fused path (no save_last: K chained behind the map encoder) only
+    # differs in the order the key projection sums its input channels
     mod.save_last = False
     out2 = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
-    assert torch.equal(out, out2)
+    _close(out2, g["x_pool"])
 
 
 def test_group_pool_golden(golden):
