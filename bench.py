@@ -33,11 +33,14 @@ from mvfusion import visibility as visibility_module     # noqa: E402
 from mvfusion.distributed import gather_pooled           # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec peak
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, dense fp32-input MFMA (v_mfma_f32_32x32x2_f32)
 VIS = dict(voxel=0.05, r_max=20, r_min=0, k_swell=1.5, d_swell=1e6, exact=True,
            camera="kitti360_perspective")
 WORKLOADS = {
     "c1": dict(channels=64, label="KITTI-360-shaped cylinder, 100k pts x 8 views 1408x376"),
     "c2": dict(channels=13, label="WildScenes-shaped scan, 300k pts x 16 views 2016x1512"),
+    "c3": dict(channels=64, label="QKVBimodalCSRPool, 500k pts x <=32 views (Poisson 4), "
+                                  "64-ch modality, 32-ch main, 8-ch mapping features, 16-ch keys"),
 }
 
 
@@ -117,6 +120,82 @@ def cpu_baseline(cfg, C_feat, target_s=12.0):
                        f"({N} pts x {V} views, map + pools), median {med:.3f} s/pass")
 
 
+def qkv_flops(N, Vw, F_main, F_map, C, D, G, inner=32):
+    """Multiply-adds x 2 of QKVBimodalCSRPool.forward (pooling.py:454-547) with a
+    DeepSetFeat map encoder: E_main, Q on N rows; mlp_elt_1, mlp_elt_2, E_mod, K,
+    the compatibilities and the weighted sum on Vw rows; mlp_set on N rows."""
+    per_point = F_main * inner + inner * inner + inner * D * G + inner * inner + inner * inner
+    per_view = (F_map * inner + inner * inner + 2 * inner * inner + inner * inner
+                + C * C + C * C + inner * D * G + D * G + C)
+    return 2 * (N * per_point + Vw * per_view)
+
+
+def run_qkv(args, rank, world, device, dist):
+    """C3: the attentive pool on synthetic CSR groups; one step = one forward."""
+    from mvfusion import pooling
+    N, F_main, F_map, Cm, D, G = 500_000, 32, 8, 64, 16, 1
+    rng = np.random.default_rng(3 + rank)
+    counts = np.minimum(rng.poisson(4, N), 32)
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(device)
+    Vw = int(ptr[-1])
+    gen = torch.Generator(device=device).manual_seed(rank)
+    x_main = torch.rand((N, F_main), device=device, generator=gen)
+    x_mod = torch.rand((Vw, Cm), device=device, generator=gen)
+    x_map = torch.rand((Vw, F_map), device=device, generator=gen)
+    labels = torch.randint(0, 19, (N,), device=device, generator=gen)
+    torch.manual_seed(0)
+    mod = pooling.QKVBimodalCSRPool(in_main=F_main, in_map=F_map, in_mod=Cm, out_mod=Cm,
+                                    nc_qk=D, num_groups=G).to(device).eval()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = mod(x_main, x_mod, x_map, ptr)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = mod(x_main, x_mod, x_map, ptr)
+    if dist is not None:
+        gather_pooled(out, labels)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return
+    # launch duration of the whole forward with HIP events on the launch stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(args.steps):
+        mod(x_main, x_mod, x_map, ptr)
+    ev[1].record()
+    torch.cuda.synchronize()
+    fwd_ms = ev[0].elapsed_time(ev[1]) / args.steps
+    flops = qkv_flops(N, Vw, F_main, F_map, Cm, D, G)
+    bytes_ = 4 * (F_main * N + (Cm + F_map) * Vw + Cm * N) + 8 * (N + 1)
+    line = {
+        "metric": "points*views mapped+fused/sec",
+        "value": world * Vw * args.steps / elapsed, "unit": "points*views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": WORKLOADS["c3"]["label"], "name": "c3", "points_per_gpu": N,
+                   "point_view_rows": Vw, "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
+        "roofline": {"bound": "mfma", "kernel": "QKVBimodalCSRPool.forward (all launches)",
+                     "achieved": flops / (fwd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
+                     "unit": "TFLOP/s", "frac": flops / (fwd_ms * 1e-3) / MFMA_F32_PEAK,
+                     "traffic": None, "flops_per_launch": flops, "kernel_ms": fwd_ms,
+                     "hbm": {"algorithmic_bytes": bytes_,
+                             "frac": bytes_ / (fwd_ms * 1e-3) / HBM_PEAK}},
+    }
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,6 +217,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     cfg = args.config
+    if cfg == "c3":
+        run_qkv(args, rank, world, device, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     C_feat = WORKLOADS[cfg]["channels"]
     sc, plan = stage_sample(cfg, seed=2 + rank, device=device)
     N, V = plan.N, plan.V
