@@ -177,6 +177,10 @@ def run_qkv(args, rank, world, device, dist):
     torch.cuda.synchronize()
     fwd_ms = ev[0].elapsed_time(ev[1]) / args.steps
     flops = qkv_flops(N, Vw, F_main, F_map, Cm, D, G)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("c3", {}).get("forward")
     bytes_ = 4 * (F_main * N + (Cm + F_map) * Vw + Cm * N) + 8 * (N + 1)
     line = {
         "metric": "points*views mapped+fused/sec",
@@ -189,7 +193,7 @@ def run_qkv(args, rank, world, device, dist):
         "roofline": {"bound": "mfma", "kernel": "QKVBimodalCSRPool.forward (all launches)",
                      "achieved": flops / (fwd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
                      "unit": "TFLOP/s", "frac": flops / (fwd_ms * 1e-3) / MFMA_F32_PEAK,
-                     "traffic": None, "flops_per_launch": flops, "kernel_ms": fwd_ms,
+                     "traffic": traffic, "flops_per_launch": flops, "kernel_ms": fwd_ms,
                      "hbm": {"algorithmic_bytes": bytes_,
                              "frac": bytes_ / (fwd_ms * 1e-3) / HBM_PEAK}},
     }

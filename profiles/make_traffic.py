@@ -1,0 +1,44 @@
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE),
+written to profiles/pmc_traffic.json for bench.py's roofline.traffic field.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte request
+as 64 bytes for wide streaming reads, so it is doubled (an upper bound for
+narrow reads).
+usage: python profiles/make_traffic.py <cfg> <fetch_dir> <write_dir> [steps_per_run]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+STAGE = {"bin_count_kernel": "bin_count", "tile_scan_kernel": "tile_scan", "bin_fill_kernel": "bin_fill",
+         "tile_zbuffer_kernel": "tile_zbuffer", "mi_centre_kernel": "centre",
+         "mi_point_mask_kernel": "point_mask", "mi_fill_kernel": "csr_fill"}
+
+
+def per_kernel(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and "mvf::" in r["Kernel_Name"]:
+                name = r["Kernel_Name"].split("mvf::")[1].split("<")[0].split("(")[0]
+                acc[name].append(float(r["Counter_Value"]) * 1024.0)
+    return acc
+
+
+cfg, fdir, wdir = sys.argv[1:4]
+fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
+out = {}
+detail = {}
+for k in sorted(set(fetch) | set(write)):
+    f = 2.0 * sum(fetch[k]) / max(len(fetch[k]), 1)
+    w = sum(write[k]) / max(len(write[k]), 1)
+    detail[k] = dict(fetch_bytes_x2=f, write_bytes=w, launches_sampled=len(fetch[k]))
+    out[STAGE.get(k, k)] = f + w
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+data = json.load(open(path)) if os.path.exists(path) else {}
+data[cfg] = out
+data[cfg + "_detail"] = detail
+json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+for k, v in out.items():
+    print(f"{k:28s} {v / 1e6:10.2f} MB per launch")
