@@ -104,33 +104,39 @@ __device__ __forceinline__ bool project_point(
     float px, float py, float pz, const mvf_view &v, const mvf_vis_params &P,
     const uint8_t *__restrict__ mask, Proj &out)
 {
+    // A point survives when it passes the range test AND every field-of-view
+    // test, so the tests may run in any order: the cheap ones (depth sign, then
+    // the image bounds) come first and the square root / float64 range compare
+    // only for what is left.  Every value is computed exactly as in the
+    // reference's order of operations.
+    const float *M = v.cam_to_world;
+    float p0, p1, p2;
+    if (P.camera == MVF_CAM_KITTI360_PERSPECTIVE) {
+        const float e0 = __fsub_rn(px, M[3]), e1 = __fsub_rn(py, M[7]), e2 = __fsub_rn(pz, M[11]);
+        p2 = __fmaf_rn(M[10], e2, __fmaf_rn(M[6], e1, __fmul_rn(M[2], e0)));
+        if (!(0.0f < p2)) return false;
+        p0 = __fmaf_rn(M[8], e2, __fmaf_rn(M[4], e1, __fmul_rn(M[0], e0)));
+        p1 = __fmaf_rn(M[9], e2, __fmaf_rn(M[5], e1, __fmul_rn(M[1], e0)));
+    } else {
+        p2 = __fadd_rn(__fmaf_rn(M[10], pz, __fmaf_rn(M[9], py, __fmul_rn(M[8], px))), M[11]);
+        if (!(0.0f < p2)) return false;
+        p0 = __fadd_rn(__fmaf_rn(M[2], pz, __fmaf_rn(M[1], py, __fmul_rn(M[0], px))), M[3]);
+        p1 = __fadd_rn(__fmaf_rn(M[6], pz, __fmaf_rn(M[5], py, __fmul_rn(M[4], px))), M[7]);
+    }
+    // field_of_view_cpu (visibility.py:395-435); float32 values compare exactly
+    // like their float64 widenings
+    const float x = __fadd_rn(__fdiv_rn(__fmul_rn(p0, v.fx), p2), v.cx);
+    if (!(0.0f <= x)) return false;
+    if (!(x < (float)P.W)) return false;
+    const float y = __fadd_rn(__fdiv_rn(__fmul_rn(p1, v.fy), p2), v.cy);
+    if (!((float)P.crop_top <= y)) return false;
+    if (!(y < (float)(P.H - P.crop_bottom))) return false;
     const float dx = __fsub_rn(px, v.img_xyz[0]);
     const float dy = __fsub_rn(py, v.img_xyz[1]);
     const float dz = __fsub_rn(pz, v.img_xyz[2]);
     const float s = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     const float d = sqrtf(s);
     if (!(P.r_min < (double)d && (double)d < P.r_max)) return false;
-    const float *M = v.cam_to_world;
-    float p0, p1, p2;
-    if (P.camera == MVF_CAM_KITTI360_PERSPECTIVE) {
-        const float e0 = __fsub_rn(px, M[3]), e1 = __fsub_rn(py, M[7]), e2 = __fsub_rn(pz, M[11]);
-        p0 = __fmaf_rn(M[8], e2, __fmaf_rn(M[4], e1, __fmul_rn(M[0], e0)));
-        p1 = __fmaf_rn(M[9], e2, __fmaf_rn(M[5], e1, __fmul_rn(M[1], e0)));
-        p2 = __fmaf_rn(M[10], e2, __fmaf_rn(M[6], e1, __fmul_rn(M[2], e0)));
-    } else {
-        p0 = __fadd_rn(__fmaf_rn(M[2], pz, __fmaf_rn(M[1], py, __fmul_rn(M[0], px))), M[3]);
-        p1 = __fadd_rn(__fmaf_rn(M[6], pz, __fmaf_rn(M[5], py, __fmul_rn(M[4], px))), M[7]);
-        p2 = __fadd_rn(__fmaf_rn(M[10], pz, __fmaf_rn(M[9], py, __fmul_rn(M[8], px))), M[11]);
-    }
-    const float x = __fadd_rn(__fdiv_rn(__fmul_rn(p0, v.fx), p2), v.cx);
-    const float y = __fadd_rn(__fdiv_rn(__fmul_rn(p1, v.fy), p2), v.cy);
-    // field_of_view_cpu (visibility.py:395-435); float32 values compare exactly
-    // like their float64 widenings
-    if (!(0.0f <= x)) return false;
-    if (!((float)P.crop_top <= y)) return false;
-    if (!(x < (float)P.W)) return false;
-    if (!(y < (float)(P.H - P.crop_bottom))) return false;
-    if (!(0.0f < p2)) return false;
     if (mask) {
         const unsigned xi = (unsigned)floorf(x), yi = (unsigned)floorf(y);
         if (!mask[(size_t)xi * P.H + yi]) return false;

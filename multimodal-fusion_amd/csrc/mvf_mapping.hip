@@ -57,14 +57,15 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
                         float &ofx, float &ofy) const {
         const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
         const mvf_view &view = views[v];
+        Proj pr;
+        if (!project_point(px, py, pz, view, P, mask, pr)) return false;
         // radius sampling of MapImages (image.py:242-245; transforms.py:332,386):
-        // float64 squared distance to the view centre <= r_max^2
+        // float64 squared distance to the view centre <= r_max^2 (tested last: it
+        // only removes points, and few reach it)
         const double ex = (double)px - view.centre[0], ey = (double)py - view.centre[1];
         double d2 = ex * ex + ey * ey;
         if (!cylinder) { const double ez = (double)pz - view.centre[2]; d2 = d2 + ez * ez; }
         if (!(d2 <= P.r_max * P.r_max)) return false;
-        Proj pr;
-        if (!project_point(px, py, pz, view, P, mask, pr)) return false;
         ox = (double)pr.x; oy = (double)pr.y; od = pr.dist; ofx = view.fx; ofy = view.fy;
         return true;
     }
@@ -117,14 +118,18 @@ __device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
     return (NCLS - 1) - (l > NCLS - 1 ? NCLS - 1 : l);
 }
 
-// Range of tile indices [lo, hi) touched by the boxes of a block (hi <= lo when
-// no thread has one).  The points of a block are neighbours in space, so the
-// range is a small part of the view's tiles and the LDS histogram only needs
-// clearing and flushing there.
-__device__ __forceinline__ void block_tile_range(bool have, int t_first, int t_last, int &lo, int &hi)
+// Rank of the thread's flag inside the block, number of flags, and the range
+// of tile indices [lo, hi) touched by the flagged threads' boxes (hi <= lo when
+// there is none), with a single barrier.  The points of a block are neighbours
+// in space, so the range is a small part of the view's tiles and the LDS
+// histogram only needs clearing and flushing there.
+struct BlockBins { unsigned rank, total; int lo, hi; };
+
+__device__ __forceinline__ BlockBins block_bins(bool have, int t_first, int t_last)
 {
-    __shared__ int s_range[2];
-    if (threadIdx.x == 0) { s_range[0] = 0x7fffffff; s_range[1] = -1; }
+    __shared__ int s_cnt[4], s_mn[4], s_mx[4];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 m = __ballot(have);
     int mn = have ? t_first : 0x7fffffff, mx = have ? t_last : -1;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -132,11 +137,21 @@ __device__ __forceinline__ void block_tile_range(bool have, int t_first, int t_l
         mn = omn < mn ? omn : mn;
         mx = omx > mx ? omx : mx;
     }
+    if (lane == 0) { s_cnt[wave] = __popcll(m); s_mn[wave] = mn; s_mx[wave] = mx; }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0 && mx >= 0) { atomicMin(&s_range[0], mn); atomicMax(&s_range[1], mx); }
-    __syncthreads();
-    lo = s_range[0];
-    hi = s_range[1] + 1;
+    BlockBins r;
+    r.rank = __popcll(m & ((1ull << lane) - 1ull));
+    r.total = 0; r.lo = 0x7fffffff; r.hi = -1;
+#pragma unroll
+    for (unsigned w = 0; w < 4; ++w) {
+        const int c = s_cnt[w];
+        if (w < wave) r.rank += c;
+        r.total += c;
+        r.lo = s_mn[w] < r.lo ? s_mn[w] : r.lo;
+        r.hi = s_mx[w] > r.hi ? s_mx[w] : r.hi;
+    }
+    r.hi += 1;
+    return r;
 }
 
 template <class Src, bool ZERO_SEEN, bool USE_LDS>
@@ -169,24 +184,21 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     const int ncnt = tiles_per_view * NCLS;
     unsigned *tc = tile_count + (size_t)v * ncnt;
+    const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
     {
         // the boxes are kept for the fill pass, packed per block
-        unsigned total;
-        const unsigned rank = block_rank_flag(have, total);
         const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
-        if (tid == 0) staged_count[blk] = total;
+        if (tid == 0) staged_count[blk] = bb.total;
         if (have) {
             TileEntry e;
             e.key = depth_key(d, (unsigned)i);
             e.xa = (uint16_t)b.xa; e.xb = (uint16_t)b.xb; e.ya = (uint16_t)b.ya; e.yb = (uint16_t)b.yb;
-            staged[blk * 256 + rank] = e;
+            staged[blk * 256 + bb.rank] = e;
         }
     }
+    if (bb.total == 0) return;
     if (USE_LDS) {
-        int lo, hi;
-        block_tile_range(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, lo, hi);
-        if (hi <= lo) return;
-        lo *= NCLS; hi *= NCLS;
+        const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
         for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
@@ -228,10 +240,8 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     const int ncnt = tiles_per_view * NCLS;
     const size_t cbase = (size_t)v * ncnt;
     if (USE_LDS) {
-        int lo, hi;
-        block_tile_range(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, lo, hi);
-        if (hi <= lo) return;
-        lo *= NCLS; hi *= NCLS;
+        const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
+        const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
         for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
@@ -435,7 +445,11 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     queue += q * ZB_QUEUE_STRIDE;
     const int tid = threadIdx.x;
     const int ly = tid & 15;
-    const int slot = ly * ZB_QUARTERS + (tid >> 4);   // entry of this lane inside a group
+    // Entry of this lane inside a group: round ly, quarter tid >> 4.  Entries are
+    // ordered by decreasing cost, so odd rounds deal the quarters in reverse
+    // order (the quarter that got the most expensive entry of a round gets the
+    // cheapest one of the next).
+    const int slot = ly * ZB_QUARTERS + ((ly & 1) ? ZB_QUARTERS - 1 - (tid >> 4) : (tid >> 4));
 
 #ifdef MVF_ZB_TIMING
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
@@ -503,38 +517,42 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
         // read out the tile and reset it for the next one: every thread owns 8
         // vertically adjacent pixels (one 64-byte piece of a column)
         if (!ZBD(4)) {
-            static_assert(ZB_THREADS * 8 == TILE * TILE, "one 8-pixel piece per thread");
-            u64 *cell = zb + (tid >> 3) * ZB_PITCH + (tid & 7) * 8;
-            unsigned id[8], left[8];
+            static_assert((TILE * TILE / 8) % ZB_THREADS == 0, "whole 8-pixel pieces per thread");
 #pragma unroll
-            for (int k = 0; k < 8; ++k) id[k] = (unsigned)cell[k];      // empty cells read 0xffffffff
-            // Winner of the same row in the column to the left.  That column
-            // belongs to lane - 8 of the same wave, whose reset below comes
-            // after this read in program order; the first 8 lanes of a wave
-            // would race with another wave and go without.
-            const bool has_left = (tid & 63) >= 8;
+            for (int piece = tid; piece < TILE * TILE / 8; piece += ZB_THREADS) {
+                u64 *cell = zb + (piece >> 3) * ZB_PITCH + (piece & 7) * 8;
+                unsigned id[8], left[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) left[k] = has_left ? (unsigned)cell[k - (int)ZB_PITCH] : 0xffffffffu;
+                for (int k = 0; k < 8; ++k) id[k] = (unsigned)cell[k];      // empty cells read 0xffffffff
+                // Winner of the same row in the column to the left.  That column
+                // belongs to lane - 8 of the same wave in the same step, whose
+                // reset below comes after this read in program order; the first
+                // 8 lanes of a wave would race with another wave and go without.
+                const bool has_left = (tid & 63) >= 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) cell[k] = ZB_EMPTY;
-            if (WRITE_IDMAP) {
-                const int gx = x0 + (tid >> 3), gy = y0 + (tid & 7) * 8;
-                if (gx < W) {
-                    unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
+                for (int k = 0; k < 8; ++k) left[k] = has_left ? (unsigned)cell[k - (int)ZB_PITCH] : 0xffffffffu;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
-                }
-            } else {
-                uint8_t *sv = seen + v;
-                // a winner is marked where neither the pixel above (inside the
-                // piece) nor the pixel to the left shows it: its top-left
-                // visible pixel always qualifies
-                unsigned prev = 0xffffffffu;
+                for (int k = 0; k < 8; ++k) cell[k] = ZB_EMPTY;
+                if (WRITE_IDMAP) {
+                    const int gx = x0 + (piece >> 3), gy = y0 + (piece & 7) * 8;
+                    if (gx < W) {
+                        unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2)) sv[(size_t)id[k] * seen_stride] = 1;
-                    prev = id[k];
+                        for (int k = 0; k < 8; ++k)
+                            if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
+                    }
+                } else {
+                    uint8_t *sv = seen + v;
+                    // a winner is marked where neither the pixel above (inside the
+                    // piece) nor the pixel to the left shows it: its top-left
+                    // visible pixel always qualifies
+                    unsigned prev = 0xffffffffu;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2))
+                            sv[(size_t)id[k] * seen_stride] = 1;
+                        prev = id[k];
+                    }
                 }
             }
         }
