@@ -24,11 +24,20 @@
 // after the first has input width <= 64; the first layer's input is streamed
 // in chunks of 64 columns and may be any width.  The host splits wider layers
 // into several launches.
+#include <stdlib.h>
+
 #include "mvf_common.h"
 
 namespace mvf {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#ifdef MVF_MLP_DEBUG
+static int g_mlp_debug;          // host side; bit 0: no output stores, bit 1: no input loads
+#define MLPD(A_, bit) ((A_).debug & (bit))
+#else
+#define MLPD(A_, bit) false
+#endif
 
 constexpr int MLP_THREADS = 256;
 constexpr int MLP_WAVES = 4;
@@ -48,6 +57,7 @@ struct MlpArgs {
     int mode;
     int nlayers;
     int vec_in, vec_out;  // 16-byte loads / stores are possible
+    int debug;            // phase switches of MVF_MLP_DEBUG builds
     i64 rows;
     mvf_mlp_layer L[MLP_MAX_LAYERS];
     float *out;
@@ -84,9 +94,14 @@ __device__ __forceinline__ float4 add4(const float4 &x, const float4 &y)
 // sources (pb = pa when there is one source); ca = columns of the first one.
 template <int MODE>
 __device__ __forceinline__ void mlp_load_row(
-    const float *pa, const float *pb, int ca, int c0, int S, float (&xr)[32])
+    const float *pa, const float *pb, int ca, int c0, int S, float (&xr)[32], bool skip)
 {
     float4 u[8], w[8];
+    if (skip) {
+#pragma unroll
+        for (int t = 0; t < 32; ++t) xr[t] = 1.f;
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int c = c0 + (4 * q < S ? 4 * q : 0);
@@ -130,32 +145,80 @@ __device__ __forceinline__ void mlp_epilogue(
     }
 }
 
-// n += W[:, 32-channel block held in acc] * acc, 16 steps in groups of 4.
-__device__ __forceinline__ void mlp_next_layer(
-    const floatx16 &acc, const float *wp, int cop2, floatx16 &n0, floatx16 &n1)
+// Activation of four neighbouring accumulators (registers 4 g .. 4 g + 3), in
+// place.  Scale and shift are already in: the weights in LDS carry the channel
+// scale and the accumulators start from the channel shift.
+__device__ __forceinline__ void mlp_epilogue4(floatx16 &acc, int g, const mvf_mlp_layer &L)
 {
-    if (cop2 > 32) {
+    if (!L.act) return;
+    if (L.slope >= 0.f && L.slope <= 1.f) {
+        // leaky(v) = max(v, slope * v) for a slope in [0, 1]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float w0[4], w1[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { w0[e] = wp[(8 * g + e) * cop2]; w1[e] = wp[(8 * g + e) * cop2 + 32]; }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], acc[4 * g + e], n0, 0, 0, 0);
-                n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], acc[4 * g + e], n1, 0, 0, 0);
-            }
-        }
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = fmaxf(acc[4 * g + e], __fmul_rn(acc[4 * g + e], L.slope));
     } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float w0[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w0[e] = wp[(8 * g + e) * cop2];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], acc[4 * g + e], n0, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            const float v = acc[4 * g + e];
+            acc[4 * g + e] = v > 0.f ? v : __fmul_rn(v, L.slope);
         }
+    }
+}
+
+// Accumulators of block nb start from the channel shifts of the layer.
+__device__ __forceinline__ void mlp_init_acc(floatx16 &acc, int nb, const float *sh, int kh)
+{
+    const float *t = sh + nb * 32 + 4 * kh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 v = *(const float4 *)(t + 8 * g);
+        acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+    }
+}
+
+// Store of the four finished channels of group g of block nb.
+__device__ __forceinline__ void mlp_store4(
+    const floatx16 &acc, int nb, int g, const MlpArgs &A, bool vec_out, int cout, i64 row, int kh)
+{
+    float *o = A.out + row * A.ldo + nb * 32 + 4 * kh + 8 * g;
+    const int c = nb * 32 + 4 * kh + 8 * g;
+    if (MLPD(A, 1)) return;
+    if (vec_out) {
+        if (c < cout) *(float4 *)o = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < cout) o[e] = acc[4 * g + e];
+    }
+}
+
+// One input block (32 channels held in acc, block nb_in of the previous layer)
+// of the next layer: the previous layer's epilogue is applied four registers at
+// a time right before the MFMAs that consume them, so its vector work hides
+// between matrix instructions.  PASS 0: n0 and n1 together; 1: n0 only (acc is
+// finished in place); 2: n1 only from the finished acc, and after every group
+// the caller's `between(g)` runs (epilogue + store of a finished n0 group).
+template <int PASS, class F>
+__device__ __forceinline__ void mlp_next_block(
+    floatx16 &acc, int nb_in, const float *wp, int cop2, bool wide_out,
+    const mvf_mlp_layer &Lprev, floatx16 &n0, floatx16 &n1, F between, int dbg = 0)
+{
+    const float *w = wp + nb_in * 32 * cop2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float w0[4], w1[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (PASS != 2) w0[e] = (dbg & 4) ? 0.5f : w[(8 * g + e) * cop2];
+            if (PASS == 2 || (PASS == 0 && wide_out)) w1[e] = (dbg & 4) ? 0.5f : w[(8 * g + e) * cop2 + 32];
+        }
+        if (PASS != 2 && !(dbg & 8)) mlp_epilogue4(acc, g, Lprev);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (PASS != 2) n0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], acc[4 * g + e], n0, 0, 0, 0);
+            if (PASS == 2 || (PASS == 0 && wide_out))
+                n1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], acc[4 * g + e], n1, 0, 0, 0);
+        }
+        between(nb_in * 4 + g);
     }
 }
 
@@ -226,15 +289,16 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         sc[idx] = s;
         sh[idx] = t;
     }
-    // resident weights: every layer but a chunked first one; rows and columns
-    // beyond the layer are zero
+    __syncthreads();
+    // resident weights (times the channel scale): every layer but a chunked first
+    // one; rows and columns beyond the layer are zero
     for (int l = (nchunks > 1 ? 1 : 0); l < nlayers; ++l) {
         const mvf_mlp_layer &L = A.L[l];
         const int kin = mlp_wrows(l, L.cin), cop = cop_of(l);
         for (int idx = tid; idx < kin * cop; idx += MLP_THREADS) {
             const int k = idx / cop, j = idx - k * cop;
             smem[(l == 0 ? woff[0] : l == 1 ? woff[1] : woff[2]) + idx] =
-                (k < L.cin && j < L.cout) ? L.weight[(size_t)j * L.cin + k] : 0.f;
+                (k < L.cin && j < L.cout) ? __fmul_rn(L.weight[(size_t)j * L.cin + k], sc[l * MLP_MAX_C + j]) : 0.f;
         }
     }
     __syncthreads();
@@ -251,9 +315,9 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         if (live_ && A.b.gather) rb = A.b.gather[row_];
         const float *pa = A.a.p + ra * A.a.ld;
         const float *pb = A.b.p ? A.b.p + rb * A.b.ld : pa;
-        if (mode == 0) mlp_load_row<0>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
-        else if (mode == 1) mlp_load_row<1>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
-        else mlp_load_row<2>(pa, pb, A.a.cols, k0 + kh * S, S, xr);
+        if (mode == 0) mlp_load_row<0>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+        else if (mode == 1) mlp_load_row<1>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+        else mlp_load_row<2>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
     };
     // With a single chunk the next tile's rows are requested right after the
     // first layer has consumed the current ones, so their latency hides behind
@@ -265,8 +329,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         const i64 row = base + wave * 32 + jrow;
         const bool live = row < A.rows;
         floatx16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+        mlp_init_acc(acc0, 0, sh, kh);
+        mlp_init_acc(acc1, 1, sh, kh);
 
         // ---- first layer: the lane's half of each 64-column chunk of its row ----
         for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -278,7 +342,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                 const mvf_mlp_layer &L = A.L[0];
                 for (int idx = tid; idx < MLP_KC * cop0; idx += MLP_THREADS) {
                     const int k = idx / cop0, j = idx - k * cop0;
-                    smem[woff[0] + idx] = (k < kc && j < L.cout) ? L.weight[(size_t)j * L.cin + k0 + k] : 0.f;
+                    smem[woff[0] + idx] = (k < kc && j < L.cout) ? __fmul_rn(L.weight[(size_t)j * L.cin + k0 + k], sc[j]) : 0.f;
                 }
             }
             const int c_lo = kh * S;                     // first column of this lane inside the chunk
@@ -306,7 +370,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                     if (4 * g < S) {
                         float w0[4], w1[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { w0[e] = wp[(4 * g + e) * cop0]; w1[e] = wp[(4 * g + e) * cop0 + 32]; }
+                        for (int e = 0; e < 4; ++e) { w0[e] = MLPD(A, 4) ? 0.5f : wp[(4 * g + e) * cop0]; w1[e] = MLPD(A, 4) ? 0.5f : wp[(4 * g + e) * cop0 + 32]; }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], xr[4 * g + e], acc0, 0, 0, 0);
@@ -327,32 +391,66 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             }
             if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
-        // ---- epilogues and the following layers, activations stay in registers ----
+        // ---- the following layers, activations stay in registers ----
+        auto nothing = [](int) {};
 #pragma unroll
-        for (int l = 0; l < (FIXED ? NL : MLP_MAX_LAYERS); ++l) {
-            if (l >= nlayers) break;
+        for (int l = 0; l + 1 < (FIXED ? NL : MLP_MAX_LAYERS); ++l) {
+            if (l + 1 >= nlayers) break;
             const mvf_mlp_layer &L = A.L[l];
-            const int cop = cop_of(l);
-            mlp_epilogue(acc0, 0, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, kh);
-            if (cop > 32) mlp_epilogue(acc1, 1, sc + l * MLP_MAX_C, sh + l * MLP_MAX_C, L, kh);
-            if (l == nlayers - 1) {
-                if (live) {
-                    mlp_store(acc0, 0, A, vec_out, L.cout, row, kh);
-                    if (cop > 32) mlp_store(acc1, 1, A, vec_out, L.cout, row, kh);
-                }
-                break;
-            }
+            const bool wide_in = cop_of(l) > 32, wide_out = cop_of(l + 1) > 32;
             const int cop2 = cop_of(l + 1);
             // the lane's register r of block nb is input channel nb * 32 + acc_channel(r, kh)
             const float *wp = smem + (l == 0 ? woff[1] : woff[2]) + (4 * kh) * cop2 + jrow;
             floatx16 n0, n1;
+            mlp_init_acc(n0, 0, sh + (l + 1) * MLP_MAX_C, kh);
+            mlp_init_acc(n1, 1, sh + (l + 1) * MLP_MAX_C, kh);
+            if (l + 2 == nlayers && wide_out) {
+                // last layer with two output blocks: n0 first, then n1 while the
+                // finished n0 is scaled and stored group by group
+                const mvf_mlp_layer &L2 = A.L[l + 1];
+                mlp_next_block<1>(acc0, 0, wp, cop2, true, L, n0, n1, nothing, A.debug);
+                if (wide_in) mlp_next_block<1>(acc1, 1, wp, cop2, true, L, n0, n1, nothing, A.debug);
+                const int per = wide_in ? 2 : 1;      // n1 groups per n0 group
+                auto drain = [&](int step) {
+                    if ((step + 1) % per == 0) {
+                        const int g = step / per;
+                        mlp_epilogue4(n0, g, L2);
+                        if (live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
+                    }
+                };
+                mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, A.debug);
+                if (wide_in) mlp_next_block<2>(acc1, 1, wp, cop2, true, L, n0, n1, drain, A.debug);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
-            mlp_next_layer(acc0, wp, cop2, n0, n1);
-            if (cop > 32) mlp_next_layer(acc1, wp + 32 * cop2, cop2, n0, n1);
+                for (int g = 0; g < 4; ++g) {
+                    mlp_epilogue4(n1, g, L2);
+                    if (live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
+                }
+                acc0 = n0; acc1 = n1;
+                goto tile_done;
+            }
+            mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, A.debug);
+            if (wide_in) mlp_next_block<0>(acc1, 1, wp, cop2, wide_out, L, n0, n1, nothing, A.debug);
             acc0 = n0;
             acc1 = n1;
         }
+        {
+            // epilogue and store of the last layer
+            const mvf_mlp_layer &L = A.L[nlayers - 1];
+            const bool wide = cop_of(nlayers - 1) > 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mlp_epilogue4(acc0, g, L);
+                if (live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
+            }
+            if (wide) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    mlp_epilogue4(acc1, g, L);
+                    if (live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
+                }
+            }
+        }
+    tile_done:;
     }
 }
 
@@ -565,6 +663,14 @@ static size_t mlp_lds_bytes(const mvf_mlp_layer *L, int n)
 
 using namespace mvf;
 
+#ifdef MVF_MLP_DEBUG
+extern "C" int mvf_debug_mlp_switch(int mask)
+{
+    g_mlp_debug = mask;
+    return 0;
+}
+#endif
+
 extern "C" int mvf_mlp_forward(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
@@ -601,6 +707,10 @@ extern "C" int mvf_mlp_forward(
     for (int l = 0; l < nlayers; ++l) A.L[l] = layers[l];
     A.out = out;
     A.ldo = ldo;
+    A.debug = 0;
+#ifdef MVF_MLP_DEBUG
+    A.debug = g_mlp_debug;
+#endif
     // 16-byte access: every chunk splits into halves of whole float4s that stay inside one source
     const bool al_a = ((uintptr_t)xa % 16 == 0) && lda % 4 == 0;
     const bool al_b = !xb || (((uintptr_t)xb % 16 == 0) && ldb % 4 == 0);
@@ -615,8 +725,12 @@ extern "C" int mvf_mlp_forward(
             cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
     }
-    const i64 per_cu = (i64)(160 * 1024 / (lds + 1024));
-    const i64 want = (rows + MLP_ROWS - 1) / MLP_ROWS, cap = (i64)cus * (per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu);
+    i64 per_cu = (i64)(160 * 1024 / (lds + 1024));
+    if (per_cu > 8) per_cu = 8;
+#ifdef MVF_MLP_DEBUG
+    if (const char *e = getenv("MVF_MLP_WGS")) per_cu = atoi(e);
+#endif
+    const i64 want = (rows + MLP_ROWS - 1) / MLP_ROWS, cap = (i64)cus * (per_cu < 1 ? 1 : per_cu > 64 ? 64 : per_cu);
     dim3 grid((unsigned)(want < cap ? want : cap));
     int wmask = 0;
     for (int l = 0; l < nlayers; ++l) wmask |= (layers[l].cout > 32 ? 1 : 0) << l;
