@@ -353,24 +353,75 @@ def deep_set_feat(x, ptr, sd, prefix, pool=("max",), fusion="concatenation",
     return mlp(x_out, sd, prefix + ".mlp_elt_2")
 
 
+def min_max_diff_set_feat(x, ptr, sd, prefix, use_min=True, use_max=True, use_num=False):
+    """MinMaxDiffSetFeat.forward, pooling.py:577-597."""
+    ptr = np.asarray(ptr, np.int64)
+    parts = [x]
+    if use_min:
+        parts.append(x - segment_gather_csr(x, ptr, "min"))
+    if use_max:
+        parts.append(x - segment_gather_csr(x, ptr, "max"))
+    if use_num:
+        cnt = ptr[1:] - ptr[:-1]
+        num = np.sqrt(np.float32(1) / (cnt.astype(np.float32) + np.float32(1e-3))).astype(np.float32)
+        parts.append(np.repeat(num, cnt).reshape(-1, 1))
+    return mlp(np.concatenate(parts, axis=1), sd, prefix + ".mlp")
+
+
+def map_encoder(x, ptr, sd, prefix, encoder="DeepSetFeat", **kw):
+    """The E_map module of the pools (pooling.py:240-241, 420-421)."""
+    if encoder == "DeepSetFeat":
+        pool = kw.get("pool", ("max",))
+        pool = tuple(pool.split("_")) if isinstance(pool, str) else tuple(pool)
+        return deep_set_feat(x, ptr, sd, prefix, pool, kw.get("fusion", "concatenation"),
+                             kw.get("use_num", False))
+    if encoder == "MinMaxDiffSetFeat":
+        return min_max_diff_set_feat(x, ptr, sd, prefix, kw.get("use_min", True),
+                                     kw.get("use_max", True), kw.get("use_num", False))
+    if encoder == "MLPSetFeat":
+        return mlp(x, sd, prefix + ".mlp")              # pooling.py:688-699
+    raise ValueError(encoder)
+
+
 def _gating(x, sd):
     """Gating.forward, pooling.py:717-723."""
     x = x * sd["G.weight"].astype(np.float32) + sd["G.bias"].astype(np.float32)
     return np.tanh(np.maximum(x, np.float32(0))).astype(np.float32)
 
 
+def _attend(xv, comp, ptr, sd, num_groups, out_mod, gating, group_scaling):
+    """pooling.py:284-300 / 514-530."""
+    att = segment_softmax_csr(comp, ptr, scaling=group_scaling)
+    x_pool = segment_csr(xv * expand_group_feat(att, num_groups, out_mod), ptr, "sum")
+    gate = None
+    if gating:
+        gate = _gating(segment_csr(comp, ptr, "max"), sd)
+        x_pool = x_pool * expand_group_feat(gate, num_groups, out_mod)
+    return x_pool, att, gate
+
+
 def qkv_pool(x_main, x_mod, x_map, ptr, sd, num_groups=1, nc_qk=8, gating=True,
              dim_scaling=True, group_scaling=False, use_num=False,
-             pool=("max",), fusion="concatenation", return_parts=False):
-    """QKVBimodalCSRPool.forward (eval, use_mod_q = use_mod_k = False,
-    map_encoder = DeepSetFeat), pooling.py:454-547."""
+             pool=("max",), fusion="concatenation", return_parts=False,
+             use_mod_q=False, use_mod_k=False, map_encoder_name="DeepSetFeat", **enc_kw):
+    """QKVBimodalCSRPool.forward (eval), pooling.py:454-547."""
     ptr = np.asarray(ptr, np.int64)
     out_mod = sd["E_mod.1.0.weight"].shape[0]
+    enc = dict(pool=pool, fusion=fusion, use_num=use_num)
+    enc.update(enc_kw)
     xm = mlp(x_main, sd, "E_main")
-    xp = deep_set_feat(x_map, ptr, sd, "E_map", pool, fusion, use_num)
+    xp = map_encoder(x_map, ptr, sd, "E_map", map_encoder_name, **enc)
     xv = mlp(x_mod, sd, "E_mod")
-    keys = linear(xp, sd["K.weight"], sd["K.bias"])
-    queries = gather_csr(linear(xm, sd["Q.weight"], sd["Q.bias"]), ptr)
+    if use_mod_k:
+        keys = linear(mlp(np.concatenate([xp, xv], axis=1), sd, "E_mix_K"),
+                      sd["K.weight"], sd["K.bias"])
+    else:
+        keys = linear(xp, sd["K.weight"], sd["K.bias"])
+    if use_mod_q:
+        xq = np.concatenate([gather_csr(xm, ptr), xv], axis=1)
+        queries = linear(mlp(xq, sd, "E_mix_Q"), sd["Q.weight"], sd["Q.bias"])
+    else:
+        queries = gather_csr(linear(xm, sd["Q.weight"], sd["Q.bias"]), ptr)
     V = keys.shape[0]
     prod = (keys.reshape(V, num_groups, nc_qk) * queries.reshape(V, num_groups, nc_qk))
     comp = prod[:, :, 0].copy()
@@ -378,12 +429,7 @@ def qkv_pool(x_main, x_mod, x_map, ptr, sd, num_groups=1, nc_qk=8, gating=True,
         comp = comp + prod[:, :, k]
     if dim_scaling:
         comp = (comp / np.float32(math.sqrt(nc_qk))).astype(np.float32)
-    att = segment_softmax_csr(comp, ptr, scaling=group_scaling)
-    x_pool = segment_csr(xv * expand_group_feat(att, num_groups, out_mod), ptr, "sum")
-    gate = None
-    if gating:
-        gate = _gating(segment_csr(comp, ptr, "max"), sd)
-        x_pool = x_pool * expand_group_feat(gate, num_groups, out_mod)
+    x_pool, att, gate = _attend(xv, comp, ptr, sd, num_groups, out_mod, gating, group_scaling)
     if return_parts:
         return dict(x_pool=x_pool, K=keys, Q=queries, C=comp, A=att, G=gate,
                     x_map=xp, x_mod=xv)
@@ -392,18 +438,21 @@ def qkv_pool(x_main, x_mod, x_map, ptr, sd, num_groups=1, nc_qk=8, gating=True,
 
 def group_pool(x_mod, x_map, ptr, sd, num_groups=1, gating=True,
                group_scaling=True, use_num=False, pool=("max",),
-               fusion="concatenation"):
-    """GroupBimodalCSRPool.forward (eval, use_mod=False), pooling.py:263-315."""
+               fusion="concatenation", use_mod=False, map_encoder_name="DeepSetFeat",
+               return_parts=False, **enc_kw):
+    """GroupBimodalCSRPool.forward (eval), pooling.py:263-315."""
     ptr = np.asarray(ptr, np.int64)
     out_mod = sd["E_mod.1.0.weight"].shape[0]
-    xp = deep_set_feat(x_map, ptr, sd, "E_map", pool, fusion, use_num)
+    enc = dict(pool=pool, fusion=fusion, use_num=use_num)
+    enc.update(enc_kw)
+    xp = map_encoder(x_map, ptr, sd, "E_map", map_encoder_name, **enc)
     xv = mlp(x_mod, sd, "E_mod")
+    if use_mod:
+        xp = mlp(np.concatenate([xp, xv], axis=1), sd, "E_mix")
     comp = linear(xp, sd["E_score.weight"], sd["E_score.bias"])
-    att = segment_softmax_csr(comp, ptr, scaling=group_scaling)
-    x_pool = segment_csr(xv * expand_group_feat(att, num_groups, out_mod), ptr, "sum")
-    if gating:
-        gate = _gating(segment_csr(comp, ptr, "max"), sd)
-        x_pool = x_pool * expand_group_feat(gate, num_groups, out_mod)
+    x_pool, att, gate = _attend(xv, comp, ptr, sd, num_groups, out_mod, gating, group_scaling)
+    if return_parts:
+        return dict(x_pool=x_pool, C=comp, A=att, G=gate)
     return x_pool
 
 

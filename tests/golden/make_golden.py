@@ -412,9 +412,59 @@ def gen_attention_pools():
          **{k: np.asarray(v) for k, v in kw.items()}, **sd)
 
 
+def gen_attention_variants():
+    """Option combinations of the attentive pools beyond the defaults: modality
+    features mixed into keys / queries / scores, the other map encoders, the
+    other DeepSetFeat fusions and pools.  Small on purpose (state dicts are
+    stored with the vectors)."""
+    import contextlib
+    import io
+    pooling = ref["pooling"]
+    rng = np.random.default_rng(21)
+    N, F_main, F_map, C = 300, 12, 8, 24
+    ptr = random_ptr(rng, N, 4)
+    Vw = int(ptr[-1])
+    x_main = rng.random((N, F_main)).astype(np.float32)
+    x_mod = rng.random((Vw, C)).astype(np.float32)
+    x_map = rng.random((Vw, F_map)).astype(np.float32)
+    variants = {
+        "qkv_usemod": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, in_map=F_map, in_mod=C, out_mod=C, num_groups=2, nc_qk=4,
+            use_mod_q=True, use_mod_k=True, gating=True, dim_scaling=True, group_scaling=True)),
+        "qkv_minmax": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, in_map=F_map, in_mod=C, out_mod=16, num_groups=1, nc_qk=8,
+            map_encoder="MinMaxDiffSetFeat", use_min=True, use_max=True, use_num=True)),
+        "qkv_residual": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, in_map=F_map, in_mod=C, num_groups=C, nc_qk=2,
+            map_encoder="DeepSetFeat", pool="max_mean_min_sum", fusion="residual")),
+        "qkv_both": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, in_map=F_map, in_mod=C, num_groups=3, nc_qk=4,
+            map_encoder="DeepSetFeat", pool="mean", fusion="both", use_num=True)),
+        "group_usemod": ("GroupBimodalCSRPool", dict(
+            in_map=F_map, in_mod=C, out_mod=C, num_groups=4, use_mod=True, gating=True,
+            group_scaling=False, map_encoder="MLPSetFeat")),
+    }
+    for name, (cls, kw) in variants.items():
+        torch.manual_seed(sum(map(ord, name)))
+        gen = torch.Generator().manual_seed(len(name))
+        mod = getattr(pooling, cls)(save_last=True, **kw).eval()
+        with torch.no_grad():
+            randomise_bn(mod, gen)
+            if mod.G is not None:
+                g = mod.G.weight.shape[1]
+                mod.G.weight.copy_(torch.rand(1, g, generator=gen) + 0.5)
+                mod.G.bias.copy_(torch.randn(1, g, generator=gen) * 0.1)
+            with contextlib.redirect_stdout(io.StringIO()):
+                out = mod(T(x_main), T(x_mod), T(x_map), T(ptr))
+        sd = {"sd." + k: v.numpy() for k, v in mod.state_dict().items()}
+        save(name, x_main=x_main, x_mod=x_mod, x_map=x_map, ptr=ptr, x_pool=out.numpy(),
+             C=mod._last_C.numpy(), A=mod._last_A.numpy(), cls=np.asarray(cls),
+             kwargs=np.asarray(repr(kw)), **sd)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "pooling", "attention_pools"]
+        "from_dense", "pooling", "attention_pools", "attention_variants"]
     for w in which:
         globals()["gen_" + w]()

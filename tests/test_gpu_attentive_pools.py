@@ -65,6 +65,25 @@ def test_group_pool_golden(golden):
     _close(out, g["x_pool"])
 
 
+@pytest.mark.parametrize("name", ["qkv_usemod", "qkv_minmax", "qkv_residual", "qkv_both",
+                                  "group_usemod"])
+def test_attention_variants_golden(golden, name):
+    """Options beyond the defaults: modality features mixed into keys / queries /
+    scores, MinMaxDiffSetFeat / MLPSetFeat encoders, the other fusions and pools."""
+    import ast
+    g = golden(name)
+    kw = ast.literal_eval(str(g["kwargs"]))
+    mod = getattr(pooling, str(g["cls"]))(save_last=True, **kw)
+    mod.load_state_dict(_sd(g), strict=True)
+    mod = mod.to(DEV).eval()
+    out = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
+    _close(out, g["x_pool"])
+    _close(mod._last_C, g["C"], rtol=1e-4)
+    _close(mod._last_A, g["A"], rtol=1e-4)
+    mod.save_last = False
+    _close(mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"])), g["x_pool"])
+
+
 def _random_module(mod, seed):
     gen = torch.Generator().manual_seed(seed)
     with torch.no_grad():

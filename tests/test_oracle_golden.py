@@ -199,3 +199,39 @@ def test_group_pool(golden):
         use_num=bool(g["use_num"]))
     scale = np.abs(g["x_pool"]).max()
     np.testing.assert_allclose(out, g["x_pool"], rtol=1e-5, atol=1e-5 * scale)
+
+
+VARIANTS = ["qkv_usemod", "qkv_minmax", "qkv_residual", "qkv_both", "group_usemod"]
+
+
+def variant_kwargs(g):
+    """Constructor kwargs stored with a variant fixture -> (class name, kwargs)."""
+    import ast
+    return str(g["cls"]), ast.literal_eval(str(g["kwargs"]))
+
+
+def oracle_variant(g):
+    cls, kw = variant_kwargs(g)
+    enc = {k: kw[k] for k in ("pool", "fusion", "use_num", "use_min", "use_max") if k in kw}
+    name = kw.get("map_encoder", "DeepSetFeat")
+    if cls == "QKVBimodalCSRPool":
+        return orc.qkv_pool(
+            g["x_main"], g["x_mod"], g["x_map"], g["ptr"], _sd(g),
+            num_groups=kw.get("num_groups", 1), nc_qk=kw.get("nc_qk", 8),
+            gating=kw.get("gating", True), dim_scaling=kw.get("dim_scaling", True),
+            group_scaling=kw.get("group_scaling", False), use_mod_q=kw.get("use_mod_q", False),
+            use_mod_k=kw.get("use_mod_k", False), map_encoder_name=name, return_parts=True, **enc)
+    return orc.group_pool(
+        g["x_mod"], g["x_map"], g["ptr"], _sd(g), num_groups=kw.get("num_groups", 1),
+        gating=kw.get("gating", True), group_scaling=kw.get("group_scaling", True),
+        use_mod=kw.get("use_mod", False), map_encoder_name=name, return_parts=True, **enc)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_attention_variants(golden, name):
+    g = golden(name)
+    parts = oracle_variant(g)
+    scale = np.abs(g["x_pool"]).max()
+    np.testing.assert_allclose(parts["C"], g["C"].reshape(parts["C"].shape), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(parts["A"], g["A"].reshape(parts["A"].shape), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(parts["x_pool"], g["x_pool"], rtol=1e-5, atol=1e-5 * scale)
