@@ -694,10 +694,25 @@ __device__ __forceinline__ unsigned seen_chunk(const uint8_t *seen, i64 seen_str
     return m;
 }
 
+// Copies the views of a call into LDS (16 bytes per thread step) and returns the
+// source with its view table there: the per-lane, per-view camera constants of
+// the kernels below are then LDS reads instead of divergent global loads.
+__device__ __forceinline__ CloudSrc views_to_lds(CloudSrc src, int V, mvf_view *lds_views)
+{
+    const uint4 *g = (const uint4 *)src.views;
+    uint4 *l = (uint4 *)lds_views;
+    for (int k = threadIdx.x; k < V * (int)(sizeof(mvf_view) / 16); k += blockDim.x) l[k] = g[k];
+    __syncthreads();
+    src.views = lds_views;
+    return src;
+}
+
 __global__ __launch_bounds__(256) void mi_centre_kernel(
     CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int V, int Hc,
     u64 *__restrict__ centre_ws, unsigned epoch)
 {
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    src = views_to_lds(src, V, (mvf_view *)dyn_lds);
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= src.n) return;
     for (int chunk = 0; chunk * 16 < V; ++chunk) {
@@ -761,6 +776,8 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    src = views_to_lds(src, V, (mvf_view *)dyn_lds);
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 i = q < num_points ? inv_ids[q] : -1;
     unsigned c = 0;
@@ -800,7 +817,9 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
     i64 *__restrict__ pointers, i64 *__restrict__ images, int16_t *__restrict__ pixels,
     float *__restrict__ features, i64 *__restrict__ counters)
 {
-    extern __shared__ int view_rank[];                   // V + 1 ranks
+    extern __shared__ __align__(16) unsigned char dyn_lds[];   // V views, then V + 1 ranks
+    src = views_to_lds(src, V, (mvf_view *)dyn_lds);
+    int *view_rank = (int *)(dyn_lds + (size_t)V * sizeof(mvf_view));
     for (int v = threadIdx.x; v <= V; v += 256) {
         int r = 0;
         for (int u = 0; u < v; ++u) r += view_seen[u] ? 1 : 0;
@@ -1168,17 +1187,17 @@ extern "C" int mvf_map_images_exact(
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
                        seen, seen_stride, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
-    hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, 0, st, src, P, seen, seen_stride, V, Hc,
+    hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, V, Hc,
                        (u64 *)centre_ws, epoch);
     prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
-    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, 0, st, src, P, seen, seen_stride, Hc,
+    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, Hc,
                        (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
