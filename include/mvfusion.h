@@ -204,6 +204,18 @@ int mvf_segment_softmax_csr(
     const float *src, int32_t G, const int64_t *ptr, int64_t nseg, float eps,
     int32_t scaling, float *out, void *stream);
 
+/* Feature-map gather fused with the atomic-level pool:
+ *   out[r][c] = reduce over p in [view_ptr[r], view_ptr[r+1]) of x[images[r]][c][pixels[p][1]][pixels[p][0]]
+ * for x [B][C][H][W] float32, i.e. BimodalCSRPool(mode)(x[mapping.feature_map_indexing],
+ * mapping.atomic_csr_indexing) without the [P][C] intermediate
+ * (core/multimodal/image.py:1272-1297, 1881-1902; modules/multimodal/pooling.py:63).
+ * pixels are (x = width index, y = height index) int16 pairs; the caller checks
+ * that images / pixels index inside x. */
+int mvf_gather_pool(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *images,
+    const int64_t *view_ptr, const int16_t *pixels, int64_t rows, int32_t reduce, float *out,
+    void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* attentive pools: QKVBimodalCSRPool / GroupBimodalCSRPool / DeepSetFeat       */
 /* ------------------------------------------------------------------------- */

@@ -140,6 +140,52 @@ __global__ __launch_bounds__(256) void segment_softmax_kernel(
     for (i64 r = a; r < b; ++r) out[(size_t)r * G + g] = __fdiv_rn(out[(size_t)r * G + g], sum);
 }
 
+// Feature-map gather fused with the atomic (pixel -> view) pool:
+// out[r][c] = reduce_{p in [vptr[r], vptr[r+1])} x[images[r]][c][py[p]][px[p]]
+// for x of shape [B][C][H][W] -- the reference materialises x[idx] as [P][C]
+// first (core/multimodal/image.py:1272-1297, 1881-1895) and pools it afterwards
+// (pooling.py:63).  A block owns 64 view rows: lane = row, so that the gathers
+// of one channel plane hit neighbouring pixels of neighbouring points, four
+// channels in flight per row; the [64][64-channel] tile goes through LDS so that
+// the output rows are written contiguously.
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_pool_kernel(
+    const float *__restrict__ x, int C, int H, int W, const i64 *__restrict__ images,
+    const i64 *__restrict__ vptr, const int16_t *__restrict__ pixels, i64 rows,
+    float *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const i64 r = (i64)blockIdx.x * 64 + row;
+    i64 a = 0, b = 0;
+    const float *plane = x;
+    if (r < rows) {
+        a = vptr[r]; b = vptr[r + 1];
+        plane = x + (size_t)images[r] * C * H * W;
+    }
+    const size_t hw = (size_t)H * W;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int c = c0 + cq; c < C && c < c0 + 64; c += 4) {
+            const float *pc = plane + (size_t)c * hw;
+            float acc = 0.f;
+            for (i64 p = a; p < b; ++p) {
+                const float v = pc[(size_t)pixels[2 * p + 1] * W + pixels[2 * p]];
+                acc = p == a ? v : fold<MODE>(acc, v);
+            }
+            if (MODE == MVF_REDUCE_MEAN && b > a) acc = __fdiv_rn(acc, (float)(b - a));
+            tile[row][c - c0] = acc;
+        }
+        __syncthreads();
+        const int cw = C - c0 < 64 ? C - c0 : 64;
+        for (int e = threadIdx.x; e < 64 * cw; e += 256) {
+            const int rr = e / cw, cc = e - rr * cw;
+            const i64 ro = (i64)blockIdx.x * 64 + rr;
+            if (ro < rows) out[(size_t)ro * C + c0 + cc] = tile[rr][cc];
+        }
+        __syncthreads();
+    }
+}
+
 static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr_log)
 {
     vec = (C % 4 == 0 && ((uintptr_t)p0 % 16 == 0) && ((uintptr_t)p1 % 16 == 0)) ? 4 : 1;
@@ -211,6 +257,30 @@ extern "C" int mvf_segment_softmax_csr(
     const i64 threads = nseg * G;
     hipLaunchKernelGGL(segment_softmax_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, G, (const i64 *)ptr, (i64)nseg, eps, scaling, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_gather_pool(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *images,
+    const int64_t *view_ptr, const int16_t *pixels, int64_t rows, int32_t reduce, float *out,
+    void *stream)
+{
+    MVF_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && rows >= 0, "gather_pool: bad shape");
+    MVF_REQUIRE(reduce >= 0 && reduce <= 3, "gather_pool: unknown reduce %d", reduce);
+    if (rows == 0) return MVF_OK;
+    MVF_REQUIRE(x && images && view_ptr && pixels && out, "gather_pool: null pointer");
+    dim3 grid(cdiv(rows, 64)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MVF_GP(M_) hipLaunchKernelGGL((gather_pool_kernel<M_>), grid, block, 0, st, x, C, H, W, \
+                                      (const i64 *)images, (const i64 *)view_ptr, pixels, (i64)rows, out)
+    switch (reduce) {
+    case MVF_REDUCE_SUM: MVF_GP(MVF_REDUCE_SUM); break;
+    case MVF_REDUCE_MEAN: MVF_GP(MVF_REDUCE_MEAN); break;
+    case MVF_REDUCE_MIN: MVF_GP(MVF_REDUCE_MIN); break;
+    default: MVF_GP(MVF_REDUCE_MAX); break;
+    }
+#undef MVF_GP
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -110,6 +110,36 @@ def segment_softmax_csr(src, csr_idx, eps=1e-12, scaling=False):
     return out
 
 
+def gather_atomic_pool(x, mappings, mode='max'):
+    """``BimodalCSRPool(mode)(None, x[mappings.feature_map_indexing], None,
+    mappings.atomic_csr_indexing)`` in one kernel: x is the [B, C, H, W] batch of
+    image feature maps, ``mappings`` an ImageMapping whose pixels are at the
+    resolution of x (core/multimodal/image.py:1272-1297, 1881-1902).  Returns the
+    view-level features [Vw, C]."""
+    if not x.is_cuda:
+        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise TypeError("gather_atomic_pool expects a float32 [B, C, H, W] feature map")
+    dev = x.device
+    x = x.detach().contiguous()
+    images = mappings.images.to(dev, torch.int64).contiguous()
+    vptr = mappings.atomic_csr_indexing.to(dev, torch.int64).contiguous()
+    pixels = mappings.pixels.to(dev, torch.int16).contiguous()
+    rows = images.shape[0]
+    B, C_, H, W = x.shape
+    if rows and (int(images.max()) >= B or int(pixels[:, 0].max()) >= W or int(pixels[:, 1].max()) >= H
+                 or int(pixels.min()) < 0 or int(images.min()) < 0):
+        raise IndexError("mappings index outside the feature map")
+    out = torch.empty((rows, C_), dtype=torch.float32, device=dev)
+    if rows:
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_gather_pool(
+                L.ptr(x), B, C_, H, W, L.ptr(images), L.ptr(vptr), L.ptr(pixels), rows,
+                L.REDUCE[mode], L.ptr(out), L.stream_ptr(dev)))
+    return out
+
+
 def group_sizes(num_elements, num_groups):
     """pooling.py:749-757."""
     sizes = torch.full(

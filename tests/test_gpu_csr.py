@@ -83,3 +83,28 @@ def test_csr_docstring_case():
     assert N(c.pointers).tolist() == [0, 2, 3, 6]
     c = c.insert_empty_groups(torch.tensor([0, 1, 3], device=DEV), num_groups=5)
     assert N(c.pointers).tolist() == [0, 2, 3, 3, 6, 6]
+
+
+@pytest.mark.parametrize("mode", ["max", "mean", "min", "sum"])
+def test_gather_atomic_pool_vs_indexing(golden, mode):
+    """Fused feature-map gather + atomic pool == x[feature_map_indexing] followed by
+    the CPU oracle's segment_csr (max / min bit-exact, sums to 1e-6)."""
+    import mvf_oracle as orc
+    from mvfusion.pooling import gather_atomic_pool
+    g = golden("from_dense")
+    m = M.ImageMapping.from_dense(
+        T(g["point_ids"]), T(g["image_ids"]), T(g["pixels"]), T(g["features"]),
+        num_points=int(g["num_points"]))
+    B = int(m.images.max()) + 1
+    Hh, Ww = int(m.pixels[:, 1].max()) + 1, int(m.pixels[:, 0].max()) + 1
+    rng = np.random.default_rng(3)
+    for C_ in (13, 70):
+        x = rng.random((B, C_, Hh, Ww)).astype(np.float32)
+        got = N(gather_atomic_pool(T(x), m, mode))
+        ib, _, ih, iw = [N(t) if torch.is_tensor(t) else t for t in m.feature_map_indexing]
+        dense = x[ib, :, ih, iw]
+        want = orc.segment_csr(dense, N(m.atomic_csr_indexing), mode)
+        if mode in ("max", "min"):
+            assert np.array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
