@@ -341,17 +341,30 @@ __device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, b
 // Scan of the [tile][class] counters, one tile per thread: exclusive offsets,
 // grand total, and the list of non-empty tiles with their entry ranges, which
 // is what the z-buffer kernel iterates over.  Every 1024-thread block first
-// re-adds the counters of the tiles in front of it (a few hundred KB of L2
-// hits at most), so a single launch needs no inter-block ordering.  tile_cur
-// is cleared here for the fill pass.
+// re-reads the counters of all tiles (a few hundred KB of L2 hits), so a single
+// launch needs no inter-block ordering.  tile_cur is cleared here for the fill
+// pass.
+//
+// The list is ordered by decreasing raster cost in half-octave buckets (the
+// order inside a bucket is arbitrary): the persistent workgroups of the
+// z-buffer kernel take tiles front to back, so the expensive tiles start first
+// and the cheap ones even out the finish times.
 struct TileDesc { unsigned begin, end, view, origin; };   // origin = x0 | y0 << 16
+constexpr int ZB_BUCKETS = 64;
+constexpr unsigned ZB_TILE_FIXED_COST = 256;    // readout + reset of a tile, in raster steps
 
-__device__ __forceinline__ u64 tile_weight(const unsigned *__restrict__ tile_count, i64 t)
+// Entries of a tile (low 32 bits) and its cost bucket + 1 (0 = empty tile) above.
+__device__ __forceinline__ u64 tile_weight(const uint4 &a, const uint4 &b)
 {
-    const uint4 a = *(const uint4 *)(tile_count + t * NCLS);
-    const uint4 b = *(const uint4 *)(tile_count + t * NCLS + 4);
-    const u64 c = (u64)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    return c | ((u64)(c != 0) << 40);          // entries in the low 40 bits, non-empty tiles above
+    const u64 n = (u64)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    if (n == 0) return 0;
+    // class k costs about 2^(NCLS - 1 - k) raster steps per entry
+    u64 w = ((u64)a.x << 7) + ((u64)a.y << 6) + ((u64)a.z << 5) + ((u64)a.w << 4) +
+            ((u64)b.x << 3) + ((u64)b.y << 2) + ((u64)b.z << 1) + (u64)b.w + ZB_TILE_FIXED_COST;
+    const int l = 63 - __clzll((long long)w);
+    int hb = 2 * l + (int)((w >> (l - 1)) & 1u);               // half octaves, >= 16
+    hb = hb > ZB_BUCKETS - 1 ? ZB_BUCKETS - 1 : hb;
+    return n | ((u64)(ZB_BUCKETS - hb) << 32);                  // bucket 0 = most expensive
 }
 
 __global__ __launch_bounds__(1024) void tile_scan_kernel(
@@ -359,21 +372,43 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
     unsigned *__restrict__ tile_cur, TileDesc *__restrict__ descs, unsigned *__restrict__ n_desc,
     i64 *__restrict__ total_out, int tiles_y, int tiles_per_view)
 {
-    const i64 t = (i64)blockIdx.x * 1024 + threadIdx.x;
-    u64 front = 0;
-    for (i64 p = threadIdx.x; p < (i64)blockIdx.x * 1024; p += 1024) front += tile_weight(tile_count, p);
+    __shared__ unsigned h_all[ZB_BUCKETS], h_front[ZB_BUCKETS], h_blk[ZB_BUCKETS], h_base[ZB_BUCKETS];
+    if (threadIdx.x < ZB_BUCKETS) h_all[threadIdx.x] = h_front[threadIdx.x] = h_blk[threadIdx.x] = 0u;
+    __syncthreads();
+    const i64 first = (i64)blockIdx.x * 1024;
+    const i64 t = first + threadIdx.x;
+    u64 front = 0, own = 0;
     uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
-    if (t < ntiles) {
-        a = *(const uint4 *)(tile_count + t * NCLS);
-        b = *(const uint4 *)(tile_count + t * NCLS + 4);
+    for (i64 p = threadIdx.x; p < ntiles; p += 1024) {
+        const uint4 pa = *(const uint4 *)(tile_count + p * NCLS);
+        const uint4 pb = *(const uint4 *)(tile_count + p * NCLS + 4);
+        const u64 w = tile_weight(pa, pb);
+        if (p == t) { a = pa; b = pb; own = w; }
+        if (w) {
+            const unsigned bk = (unsigned)(w >> 32) - 1u;
+            atomicAdd(&h_all[bk], 1u);
+            if (p < first) { atomicAdd(&h_front[bk], 1u); front += w & 0xffffffffu; }
+        }
     }
-    const u64 own = t < ntiles ? tile_weight(tile_count, t) : 0;
     u64 front_total, own_total;
     block_exclusive_scan<u64, 16>(front, front_total);
-    const u64 ex = block_exclusive_scan<u64, 16>(own, own_total) + front_total;
+    const u64 ex = block_exclusive_scan<u64, 16>(own & 0xffffffffu, own_total) + front_total;
+    // bucket bases (block_exclusive_scan ends with a barrier, h_all is complete)
+    if (threadIdx.x < 64) {
+        const unsigned c = h_all[threadIdx.x];
+        unsigned inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = __shfl_up(inc, o, 64);
+            if ((int)threadIdx.x >= o) inc += up;
+        }
+        h_base[threadIdx.x] = inc - c;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 63) *n_desc = inc;
+    }
+    __syncthreads();
     if (t < ntiles) {
         const unsigned c[NCLS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        unsigned run = (unsigned)(ex & 0xffffffffffull);
+        unsigned run = (unsigned)ex;
         const unsigned begin = run;
         unsigned o[NCLS];
 #pragma unroll
@@ -382,17 +417,18 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
         *(uint4 *)(tile_off + t * NCLS + 4) = make_uint4(o[4], o[5], o[6], o[7]);
         *(uint4 *)(tile_cur + t * NCLS) = make_uint4(0u, 0u, 0u, 0u);
         *(uint4 *)(tile_cur + t * NCLS + 4) = make_uint4(0u, 0u, 0u, 0u);
-        if (run != begin) {
+        if (own) {
+            const unsigned bk = (unsigned)(own >> 32) - 1u;
+            const unsigned slot = h_base[bk] + h_front[bk] + atomicAdd(&h_blk[bk], 1u);
             const unsigned v = (unsigned)t / (unsigned)tiles_per_view, lt = (unsigned)t - v * tiles_per_view;
             const unsigned tx = lt / (unsigned)tiles_y, ty = lt - tx * tiles_y;
-            descs[ex >> 40] = TileDesc{begin, run, v, (tx << TILE_LOG) | (ty << (TILE_LOG + 16))};
+            descs[slot] = TileDesc{begin, run, v, (tx << TILE_LOG) | (ty << (TILE_LOG + 16))};
         }
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         const u64 tot = front_total + own_total;
-        tile_off[ntiles * NCLS] = (unsigned)(tot & 0xffffffffffull);
-        *n_desc = (unsigned)(tot >> 40);
-        if (total_out) *total_out = (i64)(tot & 0xffffffffffull);
+        tile_off[ntiles * NCLS] = (unsigned)tot;
+        if (total_out) *total_out = (i64)tot;
     }
 }
 
@@ -418,8 +454,16 @@ __device__ unsigned long long g_zb_timing[8];
 #else
 #define ZBT(i)
 #endif
+#ifdef MVF_ZB_SPAN
+__device__ unsigned long long g_zb_span[2048 * 6];
+__device__ unsigned g_zb_tile[16384 * 2];
+__device__ unsigned g_zb_log[1024 * 16 * 3];            // per workgroup and tile: list position, end time, entries             // per list position: duration (10 ns), entries   // per workgroup: first / last wall clock, tiles done
+#endif
 
 template <bool WRITE_IDMAP>
+#ifdef MVF_ZB_SPAN
+__attribute__((amdgpu_num_sgpr(76)))
+#endif
 __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
     const unsigned *__restrict__ n_desc, unsigned *__restrict__ queue, i64 pair_capacity,
@@ -433,13 +477,14 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
 #ifdef MVF_ZB_DEBUG
     const int dbg_ = g_zb_debug;
 #endif
-    // Tiles are handed out dynamically.  A workgroup always knows its next two
-    // tiles: the first three are blockIdx, + G and + 2G, the following ones
-    // come from one of ZB_QUEUES ticket counters (counter q hands out the
-    // tiles 3G + q, 3G + q + ZB_QUEUES, ...; a workgroup stays with counter
-    // blockIdx % ZB_QUEUES and stops when that one runs dry).  The descriptor of the tile after the next is
-    // requested while the current tile is rasterised, and so are the first
-    // entries of the next tile, so neither load is waited for.
+    // Tiles are handed out front to back in the cost-ordered list.  A workgroup
+    // always knows its next two tiles: the first three are blockIdx, + G and
+    // + 2G, the following ones come from one of ZB_QUEUES ticket counters
+    // (counter q hands out the tiles 3G + q, 3G + q + ZB_QUEUES, ...; a
+    // workgroup stays with counter blockIdx % ZB_QUEUES and stops when that one
+    // runs dry).  The descriptor of the tile after the next is requested while
+    // the current tile is rasterised, and so are the first entries of the next
+    // tile, so neither load is waited for.
     unsigned k1 = blockIdx.x + gridDim.x, k2 = k1 + gridDim.x;
     const unsigned q = blockIdx.x % ZB_QUEUES;
     queue += q * ZB_QUEUE_STRIDE;
@@ -453,6 +498,12 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
 
 #ifdef MVF_ZB_TIMING
     long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
+#ifdef MVF_ZB_SPAN
+    const unsigned long long t_first_ = wall_clock64();
+    unsigned tiles_done_ = 0;
+    unsigned long long t_dry_ = 0, t_tile_ = t_first_, last_dur_ = 0, last_n_ = 0;
+    unsigned kc_ = blockIdx.x;
 #endif
     TileDesc d = descs[blockIdx.x];
     TileDesc d1 = d;
@@ -557,8 +608,18 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
             }
         }
         ZBT(6);
+#ifdef MVF_ZB_SPAN
+        ++tiles_done_;
+        if (k2 >= nd && t_dry_ == 0) t_dry_ = wall_clock64() | ((unsigned long long)tiles_done_ << 56);
+        { const unsigned long long now_ = wall_clock64(); last_dur_ = now_ - t_tile_; t_tile_ = now_; last_n_ = (unsigned long long)(end - begin);
+          if (tid == 0 && blockIdx.x < 1024 && tiles_done_ <= 16) { unsigned *lg_ = g_zb_log + (blockIdx.x * 16 + tiles_done_ - 1) * 3; lg_[0] = kc_; lg_[1] = (unsigned)(now_ - t_first_); lg_[2] = (unsigned)last_n_; }
+          if (tid == 0 && kc_ < 16384) { g_zb_tile[kc_ * 2] = (unsigned)last_dur_; g_zb_tile[kc_ * 2 + 1] = (unsigned)last_n_; } }
+#endif
         if (!more) break;
         if (tid == 0) s_next = 3u * gridDim.x + q + ticket * ZB_QUEUES;
+#ifdef MVF_ZB_SPAN
+        kc_ = k1;
+#endif
         k1 = k2; d = d1; d1 = d2; begin = nbegin; end = nend; raw = raw_n;
         __syncthreads();
         k2 = s_next;
@@ -567,6 +628,16 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
 #ifdef MVF_ZB_TIMING
     if ((tid & 63) == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_zb_timing[i], (unsigned long long)acc_[i]);
+#endif
+#ifdef MVF_ZB_SPAN
+    if (tid == 0 && blockIdx.x < 2048) {
+        g_zb_span[blockIdx.x * 6] = t_first_;
+        g_zb_span[blockIdx.x * 6 + 1] = wall_clock64();
+        g_zb_span[blockIdx.x * 6 + 2] = tiles_done_;
+        g_zb_span[blockIdx.x * 6 + 3] = t_dry_;
+        g_zb_span[blockIdx.x * 6 + 4] = last_dur_;
+        g_zb_span[blockIdx.x * 6 + 5] = last_n_;
+    }
 #endif
 }
 
@@ -583,6 +654,20 @@ extern "C" int mvf_debug_zb_timing(unsigned long long *out, int reset)
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zb_timing), sizeof(g_zb_timing)) != hipSuccess) return 1;
     if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_zb_timing), z, sizeof(z)) != hipSuccess) return 1; }
     return 0;
+}
+#endif
+#ifdef MVF_ZB_SPAN
+extern "C" int mvf_debug_zb_tiles(unsigned *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zb_tile), sizeof(unsigned) * 2 * n) != hipSuccess;
+}
+extern "C" int mvf_debug_zb_log(unsigned *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zb_log), sizeof(unsigned) * 1024 * 16 * 3) != hipSuccess;
+}
+extern "C" int mvf_debug_zb_span(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_zb_span), sizeof(unsigned long long) * 6 * n) != hipSuccess;
 }
 #endif
 
