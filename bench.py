@@ -240,25 +240,37 @@ def main():
     atomic_ptr = torch.arange(cap + 1, dtype=torch.int64, device=device)
     lib = L.load()
 
-    def step():
-        pointers, img_ids, pixels, feats, view_seen = plan.run()
+    def pools(res):
+        pointers, img_ids, pixels, feats, view_seen = res
         P = img_ids.shape[0]
         x_view = segment_csr(x_pix[:P], atomic_ptr[:P + 1], reduce="max")
         x_max = segment_csr(x_view, pointers, reduce="max")
         x_mean = segment_csr(x_view, pointers, reduce="mean")
         return x_max, x_mean, P
 
+    def run_steps(k):
+        """k full steps (mapping pass, size read-back, three pools each).  The
+        mapping pass of step j + 1 is enqueued before the sizes of step j are
+        waited for, so the device does not idle on the host round trip."""
+        out = None
+        if k <= 0:
+            return out
+        pending = plan.run_async()
+        for j in range(k):
+            nxt = plan.run_async() if j + 1 < k else None
+            out = pools(pending.result())
+            pending = nxt
+        return out
+
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    out = run_steps(args.warmup) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run_steps(args.steps)
     if dist is not None:
         # the path's only exchange: final gather of pooled features and labels
         feats_all, labels_all, _ = gather_pooled(torch.cat(out[:2], dim=1), labels)

@@ -116,7 +116,16 @@ class _CentreWorkspace:
 class FusedMapPlan:
     """One sample staged on the device for ``mvf_map_images_exact`` plus the
     output / workspace buffers, which are reused from run to run and grown when
-    the library reports an overflow."""
+    the library reports an overflow.
+
+    ``run()`` is the synchronous form (launch, read the data-dependent sizes
+    back, return the sliced outputs).  ``run_async()`` only enqueues the pass
+    and an asynchronous copy of the sizes to pinned host memory and returns a
+    ``PendingMap``; outputs alternate between two buffer sets, so that the pass
+    of the next sample can be enqueued before the sizes of the current one are
+    waited for and the device never idles on the host round trip."""
+
+    SLOTS = 2
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None):
@@ -128,57 +137,107 @@ class FusedMapPlan:
         self.F = 2 + sum(a is not None for a in attrs)
         self.pair_cap = pair_cap or (self.N * V // 4 + 4096)
         self.out_cap = out_cap or (self.N * V // 4 + 4096)
-        self.counters = torch.zeros(4, dtype=torch.int64, device=device)
-        self.pointers = torch.empty(num_points + 1, dtype=torch.int64, device=device)
-        self.view_seen = torch.empty(V, dtype=torch.int32, device=device)
-        self._bufs = None
+        self._slots = [None] * self.SLOTS
+        self._ws = None
+        self._turn = 0
         self.last_counts = None
 
-    def _buffers(self):
-        lib = L.load()
-        if self._bufs is None or self._bufs[0] != (self.pair_cap, self.out_cap):
+    def _slot(self, k):
+        """Output buffers of slot k: (out_cap, counters, host counters, event,
+        pointers, view_seen, images, pixels, features)."""
+        sl = self._slots[k]
+        if sl is None or sl[0] != self.out_cap:
             d = self.device
+            keep = sl[1:4] if sl is not None else (
+                torch.zeros(4, dtype=torch.int64, device=d),
+                torch.zeros(4, dtype=torch.int64).pin_memory(),
+                torch.cuda.Event())
+            sl = (self.out_cap,) + tuple(keep) + (
+                torch.empty(self.num_points + 1, dtype=torch.int64, device=d),
+                torch.empty(self.V, dtype=torch.int32, device=d),
+                torch.empty(self.out_cap, dtype=torch.int64, device=d),
+                torch.empty((self.out_cap, 2), dtype=torch.int16, device=d),
+                torch.empty((self.out_cap, self.F), dtype=torch.float32, device=d))
+            self._slots[k] = sl
+        return sl
+
+    def _workspace(self):
+        if self._ws is None or self._ws[0] != self.pair_cap:
+            lib = L.load()
             ws_bytes = lib.mvf_map_images_workspace_bytes(
                 self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
-            self._bufs = ((self.pair_cap, self.out_cap),
-                          torch.empty(self.out_cap, dtype=torch.int64, device=d),
-                          torch.empty((self.out_cap, 2), dtype=torch.int16, device=d),
-                          torch.empty((self.out_cap, self.F), dtype=torch.float32, device=d),
-                          L.workspace(ws_bytes, d))
-        return self._bufs[1:]
+            self._ws = (self.pair_cap, L.workspace(ws_bytes, self.device))
+        return self._ws[1]
 
-    def launch(self):
-        """Enqueue one fused mapping pass (no synchronisation)."""
+    def launch(self, slot=0):
+        """Enqueue one fused mapping pass into the buffers of `slot` (no
+        synchronisation).  Returns the slot's buffers."""
         lib = L.load()
         P = self.params
         Hc = P.H - P.crop_top - P.crop_bottom
         centre_ws, epoch = _CentreWorkspace.get(self.device, self.V * P.W * Hc)
-        img_ids, pixels, feats, ws = self._buffers()
+        sl = self._slot(slot)
+        _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = sl
+        ws = self._workspace()
         with torch.cuda.device(self.device):
             L.check(lib.mvf_map_images_exact(
                 L.ptr(self.pos), L.ptr(self.ids), L.ptr(self.inv), self.N, self.num_points,
                 L.ptr(self.views), self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
                 *[L.ptr(a) for a in self.attrs], self.upscale, self.downscale,
                 int(self.crop_size[0]), int(self.crop_size[1]), L.ptr(centre_ws), epoch,
-                self.pair_cap, L.ptr(self.pointers), L.ptr(img_ids), L.ptr(pixels),
-                L.ptr(feats), self.out_cap, L.ptr(self.view_seen), L.ptr(self.counters),
+                self.pair_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(pixels),
+                L.ptr(feats), self.out_cap, L.ptr(view_seen), L.ptr(counters),
                 L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
-        return img_ids, pixels, feats
+        return sl
+
+    def run_async(self):
+        """Enqueue a mapping pass and the copy of its sizes to pinned host
+        memory.  The returned PendingMap owns one of the two output buffer sets
+        until the PendingMap after the next one is created."""
+        slot = self._turn % self.SLOTS
+        self._turn += 1
+        sl = self.launch(slot)
+        with torch.cuda.device(self.device):
+            sl[2].copy_(sl[1], non_blocking=True)
+            sl[3].record(torch.cuda.current_stream(self.device))
+        return PendingMap(self, sl)
+
+    def _grow(self, n_map, pairs):
+        self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
+        self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
 
     def run(self):
         """Mapping pass + read-back of the data-dependent sizes (one
         synchronisation); repeats with larger buffers after an overflow.
         Returns pointers, images, pixels, features, view_seen."""
         for _ in range(3):
-            img_ids, pixels, feats = self.launch()
-            n_map, pairs, overflow, n_seen = self.counters.tolist()
+            _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = self.launch(0)
+            n_map, pairs, overflow, n_seen = counters.tolist()
             self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
             if not overflow:
-                return self.pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], \
-                    self.view_seen
-            self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
-            self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
+                return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
+            self._grow(n_map, pairs)
         raise L.MvfError("MapImages: buffers still too small after retries")
+
+
+class PendingMap:
+    """A mapping pass in flight (FusedMapPlan.run_async)."""
+
+    def __init__(self, plan, slot):
+        self.plan, self._slot = plan, slot
+
+    def result(self):
+        """Waits for the sizes of this pass (not for later work on the stream)
+        and returns pointers, images, pixels, features, view_seen.  After an
+        overflow the pass is repeated synchronously with larger buffers."""
+        _, _, host, event, pointers, view_seen, img_ids, pixels, feats = self._slot
+        event.synchronize()
+        n_map, pairs, overflow, n_seen = host.tolist()
+        if overflow:
+            self.plan._grow(n_map, pairs)
+            return self.plan.run()
+        self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
+        return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
 
 
 class MapImages(ImageTransform):

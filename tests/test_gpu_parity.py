@@ -237,6 +237,37 @@ def test_map_images_vs_oracle_full_size(cfg, order_kind):
     assert torch.equal(out.mappings.features, out2.mappings.features)
 
 
+def test_fused_plan_async_matches_sync():
+    """Pipelined passes (two in flight, alternating output buffers, sizes read
+    from pinned memory) return exactly what the synchronous pass returns,
+    including after an overflow of deliberately small buffers."""
+    from mvfusion import visibility as visibility_module
+    from mvfusion.transforms import MapImages
+    sc = S.make_scene("c1", seed=5, n_points=30000, n_views=4)
+    N = sc["xyz"].shape[0]
+    data, images = make_inputs(sc["xyz"], np.arange(N), sc, sc["img_size"], attrs=True)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+    model = visibility_module.SplattingVisibility(img_size=images.proj_size, exact=True, **VIS)
+    plan = t.prepare_fused(data, images, model, torch.device("cuda", 0))
+    want = [x.clone() for x in plan.run()]
+    a = plan.run_async()
+    b = plan.run_async()
+    ra = [x.clone() for x in a.result()]
+    c = plan.run_async()
+    rb = [x.clone() for x in b.result()]
+    rc = [x.clone() for x in c.result()]
+    for got in (ra, rb, rc):
+        assert len(got) == len(want)
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_, w_)
+    # too-small buffers: the pending pass reports the overflow and is repeated
+    plan.out_cap, plan.pair_cap = 16, 16
+    rd = [x.clone() for x in plan.run_async().result()]
+    for g_, w_ in zip(rd, want):
+        assert torch.equal(g_, w_)
+    assert plan.out_cap > 16 and plan.pair_cap > 16
+
+
 def test_map_images_no_mapping_raises():
     from mvfusion.transforms import MapImages
     sc = S.make_scene("c1", seed=3, n_points=2000, n_views=2)
