@@ -1,0 +1,122 @@
+"""GPU parity on the two multi-sample / dense workload shapes that are not the
+bench line: a batch of KITTI-360-shaped cylinders mapped and pooled as one
+concatenated ImageMapping, and the dense 4 MP depth-map case.  The CPU oracle
+is the checker on the same seeded inputs; view counts are reduced so that the
+oracle finishes in seconds, the per-view sizes are the full ones."""
+import numpy as np
+import pytest
+import torch
+
+import mvf_oracle as orc
+from mvfusion import synthetic as S
+from test_gpu_parity import VIS, Data, check_mapping, make_inputs, npy
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = torch.device("cuda", 0)
+
+
+def render_depth_map(xyz, sc, v):
+    """S3DIS-style depth map of view v rendered from the cloud itself: nearest
+    splat per pixel, quantised to 1/512 m as the 16-bit PNGs are, -1 = empty
+    (visibility.py:1328-1358)."""
+    W, H = sc["img_size"]
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = sc["fx"][v], sc["fy"][v], sc["mx"][v], sc["my"][v]
+    kw = {k: VIS[k] for k in ("voxel", "k_swell", "d_swell", "camera")}
+    idx, dist, x, y = orc.camera_projection(
+        xyz, sc["pos"][v].astype(np.float32), img_intrinsic_pinhole=K,
+        img_extrinsic=sc["extrinsic"][v], img_size=(W, H), r_max=VIS["r_max"], r_min=VIS["r_min"],
+        camera=VIS["camera"])
+    vi, px, py = orc.visibility_from_splatting(
+        x, y, dist, img_intrinsic_pinhole=K, img_size=(W, H), exact=False, **kw)
+    dm = np.full((W, H), -1.0, np.float32)
+    q = np.round(dist[vi].astype(np.float64) * 512.0)
+    dm[px, py] = (q / 512.0).astype(np.float32)
+    return dm
+
+
+def test_c5_depth_map_visibility_full_size():
+    """2 M points against 4 MP depth maps: projection + depth-map visibility
+    (visibility.py:592-623, 1361-1388) and the MapImages pass built on them."""
+    from mvfusion.transforms import MapImages
+    from mvfusion.visibility import camera_projection, visibility_from_depth_map
+    V = 2
+    sc = S.make_scene("c5", seed=4, n_views=V)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    assert N == 2_000_000 and tuple(sc["img_size"]) == (2304, 1728)
+    W, H = sc["img_size"]
+    depth_maps = [render_depth_map(xyz, sc, v) for v in range(V)]
+
+    # the two visibility steps on one view
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0], K[1, 1], K[0, 2], K[1, 2] = sc["fx"][0], sc["fy"][0], sc["mx"][0], sc["my"][0]
+    ref = orc.camera_projection(
+        xyz, sc["pos"][0].astype(np.float32), img_intrinsic_pinhole=K,
+        img_extrinsic=sc["extrinsic"][0], img_size=(W, H), r_max=VIS["r_max"], r_min=VIS["r_min"],
+        camera=VIS["camera"])
+    got = camera_projection(
+        T(xyz).to(DEV), T(sc["pos"][0].astype(np.float32)).to(DEV), img_intrinsic_pinhole=T(K).to(DEV),
+        img_extrinsic=T(sc["extrinsic"][0]).to(DEV), img_size=(W, H), r_max=VIS["r_max"],
+        r_min=VIS["r_min"], camera=VIS["camera"])
+    for g_, r_ in zip(got, ref):
+        assert np.array_equal(npy(g_), r_)
+    ridx, rx, ry = orc.visibility_from_depth_map(ref[2], ref[3], ref[1], depth_map=depth_maps[0],
+                                                 img_size=(W, H), depth_threshold=0.05)
+    gidx, gx, gy = visibility_from_depth_map(got[2], got[3], got[1], depth_map=T(depth_maps[0]).to(DEV),
+                                             img_size=(W, H), depth_threshold=0.05)
+    assert ridx.shape[0] > 10000
+    assert np.array_equal(npy(gidx), ridx)
+    assert np.array_equal(npy(gx), rx) and np.array_equal(npy(gy), ry)
+
+    # MapImages with DepthBasedVisibility on both views
+    vis = {k: VIS[k] for k in ("r_max", "r_min", "camera")}
+    want = orc.map_images(xyz, np.arange(N), sc, order=None, method="depth_map", ref_size=(W, H),
+                          cylinder=True, depth_maps=depth_maps, depth_threshold=0.05, **vis)
+    data, images = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=False)
+    images.depth_maps = [T(d).to(DEV) for d in depth_maps]
+    t = MapImages(method="DepthBasedVisibility", cylinder=True, point_order="index",
+                  depth_threshold=0.05, **vis)
+    _, out = t(data, images)
+    check_mapping(out.mappings, want)
+
+
+def test_c4_batch_of_cylinders():
+    """Per-GPU share of the 64-cylinder batch: every cylinder mapped on its own,
+    the mappings concatenated (csr.py:347-416, image.py:1627-1682), pixel
+    features gathered from the stacked feature maps and pooled to views and
+    points in one launch set; against the oracle per cylinder."""
+    from mvfusion.mapping import ImageMappingBatch
+    from mvfusion.pooling import BimodalCSRPool, gather_atomic_pool
+    from mvfusion.transforms import MapImages, kdtree_order
+    n_samples, C_feat = 3, 5
+    rng = np.random.default_rng(11)
+    maps, feats, refs = [], [], []
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+    for k in range(n_samples):
+        sc = S.make_scene("c1", seed=20 + k)
+        xyz = sc["xyz"]
+        N = xyz.shape[0]
+        W, H = sc["img_size"]
+        order = kdtree_order(T(xyz), True).numpy()
+        data, images = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=False, order=order)
+        _, out = t(data, images)
+        ref = orc.map_images(xyz, np.arange(N), sc, order=order, ref_size=(W, H), cylinder=True,
+                             exact=True, **VIS)
+        check_mapping(out.mappings, ref)
+        x = rng.random((out.num_views, C_feat, H, W)).astype(np.float32)
+        maps.append(out.mappings.to(DEV))
+        feats.append(x)
+        # oracle pooling of this cylinder: gather, pixel -> view max, view -> point max
+        pix = ref["pixels"].astype(np.int64)
+        img_of_pixel = np.repeat(ref["images"], np.diff(ref["view_pointers"]))
+        dense = x[img_of_pixel, :, pix[:, 1], pix[:, 0]]
+        xv = orc.segment_csr(dense, ref["view_pointers"], "max")
+        refs.append(orc.segment_csr(xv, ref["pointers"], "max"))
+    batch = ImageMappingBatch.from_csr_list(maps)
+    x_all = T(np.concatenate(feats, 0)).to(DEV)
+    assert int(batch.images.max()) == x_all.shape[0] - 1
+    x_view = gather_atomic_pool(x_all, batch, "max")
+    x_point = BimodalCSRPool(mode="max")(None, x_view, None, batch.view_csr_indexing)
+    assert np.array_equal(npy(x_point), np.concatenate(refs, 0))
