@@ -78,8 +78,10 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
 // points of a block touch few tiles.  Tile counters are therefore first
 // accumulated in an LDS histogram of the view's tiles and flushed with one
 // global atomic per touched tile: global atomics on the hot tile counters
-// otherwise serialise at the memory side.  Views whose counters do not fit the
-// LDS histogram use global atomics directly (USE_LDS = false).
+// otherwise serialise at the memory side.  The histogram covers the block's
+// range of touched tile indices (BIN_LDS counters, 8 KB, so that LDS does not
+// limit the number of resident blocks); a block whose range is wider uses
+// global atomics directly.
 //
 // Inside a tile the entries are grouped by decreasing clipped pixel count
 // (NCLS size classes, a factor 2 apart): the z-buffer kernel deals consecutive
@@ -94,7 +96,8 @@ constexpr int NCLS = 8;
 constexpr int ZB_QUEUES = 32;
 constexpr int ZB_QUEUE_STRIDE = 32;
 constexpr int BIN_TAIL = ZB_QUEUE_STRIDE * (ZB_QUEUES + 1);
-constexpr int BIN_MAX_COUNTERS = 12288;      // LDS histogram entries per block (48 KB)
+constexpr int BIN_LDS = 2048;                // LDS histogram entries per block, fused path (points in spatial order)
+constexpr int BIN_LDS_WIDE = 12288;          // single-view entry point: points in any order (48 KB)
 
 // Raster cost of a (splat, tile) pair: atomic instructions a row of 16 lanes
 // needs for the clipped box of cw x ch pixels.  The lanes cover 2^lg >= ch rows
@@ -154,14 +157,14 @@ __device__ __forceinline__ BlockBins block_bins(bool have, int t_first, int t_la
     return r;
 }
 
-template <class Src, bool ZERO_SEEN, bool USE_LDS>
+template <class Src, bool ZERO_SEEN, int NH>
 __global__ __launch_bounds__(256) void bin_count_kernel(
     Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
     unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride,
     i64 *__restrict__ zero_counters, int *__restrict__ zero_view_seen, int V,
     TileEntry *__restrict__ staged, unsigned *__restrict__ staged_count)
 {
-    extern __shared__ unsigned hist[];
+    __shared__ unsigned hist[NH];
     const int tid = threadIdx.x;
     const i64 i = (i64)blockIdx.x * 256 + tid;
     const int v = blockIdx.y;
@@ -197,18 +200,18 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
         }
     }
     if (bb.total == 0) return;
-    if (USE_LDS) {
-        const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
-        for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
+    const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
+    if (hi - lo <= NH) {
+        for (int t = tid; t < hi - lo; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
                 for (int ty = ty0; ty <= ty1; ++ty)
-                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
+                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty) - lo], 1u);
         __syncthreads();
-        for (int t = lo + tid; t < hi; t += 256) {
+        for (int t = tid; t < hi - lo; t += 256) {
             const unsigned c = hist[t];
-            if (c) atomicAdd(&tc[t], c);
+            if (c) atomicAdd(&tc[lo + t], c);
         }
     } else if (have) {
         for (int tx = tx0; tx <= tx1; ++tx)
@@ -217,14 +220,14 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     }
 }
 
-template <bool USE_LDS>
+template <int NH>
 __global__ __launch_bounds__(256) void bin_fill_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
     int tiles_y, int tiles_per_view,
     const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
     TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
 {
-    extern __shared__ unsigned hist[];   // per (tile, class): count, then absolute write cursor
+    __shared__ unsigned hist[NH];        // per (tile, class): count, then absolute write cursor
     const int tid = threadIdx.x;
     const int v = blockIdx.y;
     const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
@@ -239,26 +242,26 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     const int ncnt = tiles_per_view * NCLS;
     const size_t cbase = (size_t)v * ncnt;
-    if (USE_LDS) {
-        const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
-        const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
-        for (int t = lo + tid; t < hi; t += 256) hist[t] = 0;
+    const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
+    const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
+    if (hi - lo <= NH) {
+        for (int t = tid; t < hi - lo; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
                 for (int ty = ty0; ty <= ty1; ++ty)
-                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty)], 1u);
+                    atomicAdd(&hist[(tx * tiles_y + ty) * NCLS + size_class(b, tx, ty) - lo], 1u);
         __syncthreads();
         // one global reservation per touched counter; hist becomes the write cursor
-        for (int t = lo + tid; t < hi; t += 256) {
+        for (int t = tid; t < hi - lo; t += 256) {
             const unsigned c = hist[t];
-            if (c) hist[t] = tile_off[cbase + t] + atomicAdd(&tile_cur[cbase + t], c);
+            if (c) hist[t] = tile_off[cbase + lo + t] + atomicAdd(&tile_cur[cbase + lo + t], c);
         }
         __syncthreads();
         if (have)
             for (int tx = tx0; tx <= tx1; ++tx)
                 for (int ty = ty0; ty <= ty1; ++ty) {
-                    const int t = (tx * tiles_y + ty) * NCLS + size_class(b, tx, ty);
+                    const int t = (tx * tiles_y + ty) * NCLS + size_class(b, tx, ty) - lo;
                     const i64 pos = (i64)atomicAdd(&hist[t], 1u);
                     if (pos < pair_capacity) entries[pos] = e;
                     else *overflow = 1;
@@ -1088,26 +1091,14 @@ extern "C" int mvf_splat_visibility(
 
     ArraySrc src{x_proj, y_proj, dist, fx, fy, (i64)m};
     dim3 grid_m(cdiv(m, 256), 1), block(256);
-    if (ncnt <= BIN_MAX_COUNTERS)
-        hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, true>), grid_m, block,
-                           (size_t)ncnt * sizeof(unsigned), st, src, P, tiles_y, (int)tiles,
-                           tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0,
-                           staged, staged_count);
-    else
-        hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, false>), grid_m, block, 0, st, src, P,
-                           tiles_y, (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0,
-                           (i64 *)nullptr, (int *)nullptr, 0, staged, staged_count);
+    hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, BIN_LDS_WIDE>), grid_m, block, 0, st, src, P, tiles_y,
+                       (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0,
+                       staged, staged_count);
     // tile_count[tiles] doubles as the number of non-empty tiles
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, (int)tiles);
-    if (ncnt <= BIN_MAX_COUNTERS)
-        hipLaunchKernelGGL((bin_fill_kernel<true>), grid_m, block,
-                           (size_t)ncnt * sizeof(unsigned), st, staged, staged_count, tiles_y, (int)tiles,
-                           tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
-    else
-        hipLaunchKernelGGL((bin_fill_kernel<false>), grid_m, block, 0, st, staged, staged_count, tiles_y,
-                           (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity,
-                           (i64 *)counters + 2);
+    hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS_WIDE>), grid_m, block, 0, st, staged, staged_count, tiles_y,
+                       (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     if (P.exact) {
         hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
@@ -1244,29 +1235,15 @@ extern "C" int mvf_map_images_exact(
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
-    const bool lds_bins = tiles_per_view * NCLS <= BIN_MAX_COUNTERS;
-    if (lds_bins)
-        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, true>), grid_nv, block,
-                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, src, P, tiles_y,
-                           tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V,
-                           staged, staged_count);
-    else
-        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, false>), grid_nv, block, 0, st, src, P,
-                           tiles_y, tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters,
-                           view_seen, V, staged, staged_count);
+    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
+                       tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
+                       staged_count);
     prof_mark("bin_count", st);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, tiles_per_view);
     prof_mark("tile_scan", st);
-    if (lds_bins)
-        hipLaunchKernelGGL((bin_fill_kernel<true>), grid_nv, block,
-                           (size_t)tiles_per_view * NCLS * sizeof(unsigned), st, staged, staged_count,
-                           tiles_y, tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
-                           (i64 *)counters + 2);
-    else
-        hipLaunchKernelGGL((bin_fill_kernel<false>), grid_nv, block, 0, st, staged, staged_count,
-                           tiles_y, tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity,
-                           (i64 *)counters + 2);
+    hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, staged, staged_count, tiles_y,
+                       tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,

@@ -20,7 +20,7 @@ for name, chans, rows in [("E_mod 64-64-64", [64, 64, 64], 2_000_000),
     if "K" in name:
         specs = specs + [dense.linear_layer(torch.nn.Linear(32, 16).to(dev))]
     x = torch.rand((rows, chans[0]), device=dev)
-    for mask, label in [(0, "full"), (3, "no loads, no stores"), (7, "+ no LDS weight reads"), (15, "+ no activation")]:
+    for mask, label in [(0, "full"), (1, "no loads"), (2, "no stores"), (3, "no loads, no stores"), (7, "+ no LDS weight reads"), (15, "+ no activation")]:
         lib.mvf_debug_mlp_switch(mask)
         for _ in range(2):
             dense.run_layers(specs, x)
