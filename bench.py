@@ -197,6 +197,26 @@ def run_qkv(args, rank, world, device, dist):
                      "hbm": {"algorithmic_bytes": bytes_,
                              "frac": bytes_ / (fwd_ms * 1e-3) / HBM_PEAK}},
     }
+    if not args.no_cpu_baseline:
+        # the oracle's numpy restatement of the same forward on the first 50k points
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import mvf_oracle as orc
+        n_cpu = 50_000
+        rows_cpu = int(ptr[n_cpu])
+        sd = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+        inputs = (x_main[:n_cpu].cpu().numpy(), x_mod[:rows_cpu].cpu().numpy(),
+                  x_map[:rows_cpu].cpu().numpy(), ptr[:n_cpu + 1].cpu().numpy())
+        want = orc.qkv_pool(*inputs, sd, num_groups=G, nc_qk=D)
+        ts = []
+        for _ in range(3):
+            c0 = time.perf_counter()
+            orc.qkv_pool(*inputs, sd, num_groups=G, nc_qk=D)
+            ts.append(time.perf_counter() - c0)
+        err = float(np.abs(out[:n_cpu].cpu().numpy() - want).max() / max(np.abs(want).max(), 1e-30))
+        line["cpu_baseline"] = {
+            "value": rows_cpu / sorted(ts)[1], "unit": "points*views/s", "cores": 1, "kind": "port",
+            "sample": f"oracle QKV forward on the first {n_cpu} points ({rows_cpu} rows) of the same "
+                      f"workload, median of 3: {sorted(ts)[1]:.3f} s; GPU output matches it to {err:.1e} (rel. to max)"}
     print(json.dumps(line))
 
 
