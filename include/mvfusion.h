@@ -204,6 +204,18 @@ int mvf_segment_softmax_csr(
     const float *src, int32_t G, const int64_t *ptr, int64_t nseg, float eps,
     int32_t scaling, float *out, void *stream);
 
+/* Both pooling levels of the fusion in one pass over src:
+ *   out_x = segment_csr(segment_csr(src, inner_ptr, inner_reduce), outer_ptr, reduce_x)
+ * i.e. BimodalCSRPool(reduce_x)(.., BimodalCSRPool(inner_reduce)(.., src, .., atomic_csr_indexing),
+ * .., view_csr_indexing) for x = a and, when out_b is not null, x = b
+ * (modules/multimodal/pooling.py:14-71 applied at the atomic and at the view level).
+ * inner_ptr: [n_inner + 1] rows of src per inner segment; outer_ptr: [n_outer + 1]
+ * inner segments per outer segment.  Results equal the two separate calls bit for bit. */
+int mvf_segment_csr_two_level(
+    const float *src, int64_t rows, int32_t C, const int64_t *inner_ptr, int64_t n_inner,
+    int32_t inner_reduce, const int64_t *outer_ptr, int64_t n_outer, int32_t reduce_a, float *out_a,
+    int32_t reduce_b, float *out_b, void *stream);
+
 /* Feature-map gather fused with the atomic-level pool:
  *   out[r][c] = reduce over p in [view_ptr[r], view_ptr[r+1]) of x[images[r]][c][pixels[p][1]][pixels[p][0]]
  * for x [B][C][H][W] float32, i.e. BimodalCSRPool(mode)(x[mapping.feature_map_indexing],

@@ -93,6 +93,82 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
     }
 }
 
+// Two pooling levels in one pass:
+//   out_x = segment_csr(segment_csr(src, inner_ptr, INNER), outer_ptr, reduce_x)
+// for up to two outer reductions, without the [n_inner][C] intermediate and
+// with src read once.  Each inner segment is folded in row order and fed to
+// running sum / min / max accumulators in inner-segment order: the same
+// operations in the same order as the two separate passes, so the results are
+// identical.
+template <int MODE> __device__ __forceinline__ void fold_first_v(float &a, const float &x, bool first) { a = first ? x : fold<MODE>(a, x); }
+template <int MODE> __device__ __forceinline__ void fold_first_v(float4 &a, const float4 &x, bool first)
+{
+    a.x = first ? x.x : fold<MODE>(a.x, x.x); a.y = first ? x.y : fold<MODE>(a.y, x.y);
+    a.z = first ? x.z : fold<MODE>(a.z, x.z); a.w = first ? x.w : fold<MODE>(a.w, x.w);
+}
+
+template <int VEC>
+__device__ __forceinline__ typename Vec<VEC>::T pick_outer(
+    int reduce, const typename Vec<VEC>::T &sum, const typename Vec<VEC>::T &mn,
+    const typename Vec<VEC>::T &mx, i64 count)
+{
+    typename Vec<VEC>::T r;
+    zero_v(r);
+    if (count > 0) {
+        r = reduce == MVF_REDUCE_MAX ? mx : reduce == MVF_REDUCE_MIN ? mn : sum;
+        if (reduce == MVF_REDUCE_MEAN) scale_v(r, (float)count);
+    }
+    return r;
+}
+
+// The output is walked like segment_csr's: a thread owns one (outer segment,
+// column vector) pair, consecutive threads own consecutive vectors.  Inner
+// segments are taken TL_VU at a time: their pointers and their first rows are
+// loaded together (independent loads: the chain outer pointer -> inner pointer
+// -> row is latency-bound otherwise), the folds happen in inner-segment order
+// afterwards.
+constexpr int TL_VU = 4;
+
+template <int VEC, int INNER>
+__global__ __launch_bounds__(256) void two_level_pool_kernel(
+    const float *__restrict__ src, int C, const i64 *__restrict__ inner_ptr,
+    const i64 *__restrict__ outer_ptr, i64 n_outer, int reduce_a, float *__restrict__ out_a,
+    int reduce_b, float *__restrict__ out_b)
+{
+    typedef typename Vec<VEC>::T V;
+    const unsigned cv = (unsigned)(C / VEC);
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_outer * cv) return;
+    const i64 seg = e / cv;
+    const V *s = (const V *)src + (unsigned)(e - seg * cv);
+    const i64 va = outer_ptr[seg], vb = outer_ptr[seg + 1];
+    V sum, mn, mx;
+    zero_v(sum); zero_v(mn); zero_v(mx);
+    for (i64 r = va; r < vb; r += TL_VU) {
+        i64 q[TL_VU + 1];
+#pragma unroll
+        for (int u = 0; u <= TL_VU; ++u) q[u] = inner_ptr[r + u < vb ? r + u : vb];
+        V acc[TL_VU];
+#pragma unroll
+        for (int u = 0; u < TL_VU; ++u) {
+            zero_v(acc[u]);
+            if (r + u < vb && q[u + 1] > q[u]) acc[u] = s[(size_t)q[u] * cv];
+        }
+#pragma unroll
+        for (int u = 0; u < TL_VU; ++u) {
+            if (r + u >= vb) break;
+            for (i64 p = q[u] + 1; p < q[u + 1]; ++p) fold_v<INNER>(acc[u], s[(size_t)p * cv]);
+            if (INNER == MVF_REDUCE_MEAN && q[u + 1] > q[u]) scale_v(acc[u], (float)(q[u + 1] - q[u]));
+            const bool first = r + u == va;
+            fold_first_v<MVF_REDUCE_SUM>(sum, acc[u], first);
+            fold_first_v<MVF_REDUCE_MIN>(mn, acc[u], first);
+            fold_first_v<MVF_REDUCE_MAX>(mx, acc[u], first);
+        }
+    }
+    ((V *)out_a)[e] = pick_outer<VEC>(reduce_a, sum, mn, mx, vb - va);
+    if (out_b) ((V *)out_b)[e] = pick_outer<VEC>(reduce_b, sum, mn, mx, vb - va);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void gather_csr_kernel(
     const float *__restrict__ src, int C, const i64 *__restrict__ ptr, i64 nseg,
@@ -281,6 +357,37 @@ extern "C" int mvf_gather_pool(
     default: MVF_GP(MVF_REDUCE_MAX); break;
     }
 #undef MVF_GP
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_segment_csr_two_level(
+    const float *src, int64_t rows, int32_t C, const int64_t *inner_ptr, int64_t n_inner,
+    int32_t inner_reduce, const int64_t *outer_ptr, int64_t n_outer, int32_t reduce_a, float *out_a,
+    int32_t reduce_b, float *out_b, void *stream)
+{
+    MVF_REQUIRE(rows >= 0 && C >= 1 && n_inner >= 0 && n_outer >= 0, "segment_csr_two_level: bad shape");
+    MVF_REQUIRE(inner_reduce >= 0 && inner_reduce <= 3 && reduce_a >= 0 && reduce_a <= 3 &&
+                reduce_b >= 0 && reduce_b <= 3, "segment_csr_two_level: unknown reduce");
+    if (n_outer == 0) return MVF_OK;
+    MVF_REQUIRE(inner_ptr && outer_ptr && out_a && (rows == 0 || src), "segment_csr_two_level: null pointer");
+    int vec = C % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)out_a % 16 == 0 &&
+              (!out_b || (uintptr_t)out_b % 16 == 0) ? 4 : 1;
+    dim3 grid(cdiv(n_outer * (C / vec), 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MVF_TL(V_, M_) \
+    hipLaunchKernelGGL((two_level_pool_kernel<V_, M_>), grid, block, 0, st, src, C, (const i64 *)inner_ptr, \
+                       (const i64 *)outer_ptr, (i64)n_outer, reduce_a, out_a, reduce_b, out_b)
+#define MVF_TL_MODE(V_)                                            \
+    switch (inner_reduce) {                                        \
+    case MVF_REDUCE_SUM: MVF_TL(V_, MVF_REDUCE_SUM); break;        \
+    case MVF_REDUCE_MEAN: MVF_TL(V_, MVF_REDUCE_MEAN); break;      \
+    case MVF_REDUCE_MIN: MVF_TL(V_, MVF_REDUCE_MIN); break;        \
+    default: MVF_TL(V_, MVF_REDUCE_MAX); break;                    \
+    }
+    if (vec == 4) { MVF_TL_MODE(4) } else { MVF_TL_MODE(1) }
+#undef MVF_TL_MODE
+#undef MVF_TL
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -54,6 +54,33 @@ def segment_csr(src, indptr, out=None, reduce="sum"):
     return res
 
 
+def segment_csr_two_level(src, inner_ptr, outer_ptr, inner="max", outer=("max",)):
+    """``segment_csr(segment_csr(src, inner_ptr, inner), outer_ptr, o)`` for the one
+    or two reductions ``o`` in ``outer``, in a single pass over ``src`` (the
+    pixel -> view and view -> point pools of BimodalCSRPool, pooling.py:14-71,
+    without the view-level intermediate).  Returns a tuple of [n_outer, C]
+    tensors, bit-identical to the separate calls."""
+    if isinstance(outer, str):
+        outer = (outer,)
+    if not 1 <= len(outer) <= 2:
+        raise ValueError("one or two outer reductions")
+    src_c, iptr = _prep(src, inner_ptr)
+    _, optr = _prep(src, outer_ptr)
+    if src_c.dim() != 2:
+        raise NotImplementedError("segment_csr_two_level expects a 2D source")
+    n_inner, n_outer = iptr.shape[0] - 1, optr.shape[0] - 1
+    rows, C_ = src_c.shape
+    outs = [torch.empty((n_outer, C_), dtype=torch.float32, device=src_c.device) for _ in outer]
+    if n_outer > 0 and C_ > 0:
+        lib = L.load()
+        with torch.cuda.device(src_c.device):
+            L.check(lib.mvf_segment_csr_two_level(
+                L.ptr(src_c), rows, C_, L.ptr(iptr), n_inner, L.REDUCE[inner], L.ptr(optr), n_outer,
+                L.REDUCE[outer[0]], L.ptr(outs[0]), L.REDUCE[outer[-1]],
+                L.ptr(outs[1]) if len(outs) == 2 else None, L.stream_ptr(src_c.device)))
+    return tuple(outs)
+
+
 def gather_csr(src, csr_idx):
     """Gather index-level src values into element-level values based on CSR
     indices (pooling.py:825-853)."""

@@ -108,3 +108,32 @@ def test_gather_atomic_pool_vs_indexing(golden, mode):
             assert np.array_equal(got, want)
         else:
             np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("inner", ["max", "mean", "min", "sum"])
+def test_segment_csr_two_level_equals_two_passes(inner):
+    """One-pass two-level pool == two segment_csr calls, bit for bit, and == the
+    CPU oracle (max / min exact, sums to 1e-6); empty inner and outer segments,
+    13 and 64 channels."""
+    import mvf_oracle as orc
+    from mvfusion.pooling import segment_csr, segment_csr_two_level
+    rng = np.random.default_rng(7)
+    n_outer = 5000
+    outer_sizes = rng.integers(0, 6, n_outer)
+    n_inner = int(outer_sizes.sum())
+    inner_sizes = rng.integers(0, 4, n_inner)
+    optr = np.concatenate([[0], np.cumsum(outer_sizes)]).astype(np.int64)
+    iptr = np.concatenate([[0], np.cumsum(inner_sizes)]).astype(np.int64)
+    for C_ in (13, 64):
+        x = (rng.random((int(iptr[-1]), C_)) - 0.5).astype(np.float32)
+        mid = segment_csr(T(x), T(iptr), reduce=inner)
+        for outer in (("max", "mean"), ("min", "sum"), ("mean",)):
+            got = segment_csr_two_level(T(x), T(iptr), T(optr), inner=inner, outer=outer)
+            assert len(got) == len(outer)
+            for g_, o_ in zip(got, outer):
+                assert torch.equal(g_, segment_csr(mid, T(optr), reduce=o_))
+                want = orc.segment_csr(orc.segment_csr(x, iptr, inner), optr, o_)
+                if inner in ("max", "min") and o_ in ("max", "min"):
+                    assert np.array_equal(N(g_), want)
+                else:
+                    np.testing.assert_allclose(N(g_), want, rtol=1e-6, atol=1e-6)
