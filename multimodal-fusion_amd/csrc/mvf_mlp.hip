@@ -599,17 +599,22 @@ __global__ __launch_bounds__(256) void attention_pool_kernel(
     }
 #pragma unroll
     for (int k = 0; k < ATT_ILP; ++k) {
-        i64 r = a[k] + 1;
-        for (; r + 4 <= b[k]; r += 4) {
+        // four rows at a time, loaded together (rows past the end predicated off),
+        // accumulated in row order
+        for (i64 r = a[k] + 1; r < b[k]; r += 4) {
             const V *q = xs + (size_t)r * cv + c[k];
             const float *w = att + (size_t)r * G + g[k];
-            const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
-            const float w0 = w[0], w1 = w[G], w2 = w[2 * G], w3 = w[3 * G];
-            acc[k] = AV::fma_(acc[k], x0, w0); acc[k] = AV::fma_(acc[k], x1, w1);
-            acc[k] = AV::fma_(acc[k], x2, w2); acc[k] = AV::fma_(acc[k], x3, w3);
+            const bool v1 = r + 1 < b[k], v2 = r + 2 < b[k], v3 = r + 3 < b[k];
+            const V x0 = q[0];
+            const V x1 = v1 ? q[(size_t)cv] : AV::zero();
+            const V x2 = v2 ? q[2 * (size_t)cv] : AV::zero();
+            const V x3 = v3 ? q[3 * (size_t)cv] : AV::zero();
+            const float w0 = w[0], w1 = v1 ? w[G] : 0.f, w2 = v2 ? w[2 * G] : 0.f, w3 = v3 ? w[3 * G] : 0.f;
+            acc[k] = AV::fma_(acc[k], x0, w0);
+            if (v1) acc[k] = AV::fma_(acc[k], x1, w1);
+            if (v2) acc[k] = AV::fma_(acc[k], x2, w2);
+            if (v3) acc[k] = AV::fma_(acc[k], x3, w3);
         }
-        for (; r < b[k]; ++r)
-            acc[k] = AV::fma_(acc[k], xs[(size_t)r * cv + c[k]], att[(size_t)r * G + g[k]]);
         if (e0 + k * 256 < total) {
             if (gate) acc[k] = AV::mul(acc[k], gate[(size_t)s[k] * G + g[k]]);
             o[e0 + k * 256] = acc[k];

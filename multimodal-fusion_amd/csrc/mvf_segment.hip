@@ -79,14 +79,21 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
     }
 #pragma unroll
     for (int k = 0; k < SEG_ILP; ++k) {
-        i64 r = a[k] + 1;
-        for (; r + 4 <= b[k]; r += 4) {
+        // four rows at a time, loaded together (rows past the end predicated off),
+        // folded in row order
+        for (i64 r = a[k] + 1; r < b[k]; r += 4) {
             const V *q = s + (size_t)r * cv + c[k];
-            const V x0 = q[0], x1 = q[(size_t)cv], x2 = q[2 * (size_t)cv], x3 = q[3 * (size_t)cv];
-            fold_v<MODE>(acc[k], x0); fold_v<MODE>(acc[k], x1);
-            fold_v<MODE>(acc[k], x2); fold_v<MODE>(acc[k], x3);
+            const bool v1 = r + 1 < b[k], v2 = r + 2 < b[k], v3 = r + 3 < b[k];
+            V x0 = q[0], x1, x2, x3;
+            zero_v(x1); zero_v(x2); zero_v(x3);
+            if (v1) x1 = q[(size_t)cv];
+            if (v2) x2 = q[2 * (size_t)cv];
+            if (v3) x3 = q[3 * (size_t)cv];
+            fold_v<MODE>(acc[k], x0);
+            if (v1) fold_v<MODE>(acc[k], x1);
+            if (v2) fold_v<MODE>(acc[k], x2);
+            if (v3) fold_v<MODE>(acc[k], x3);
         }
-        for (; r < b[k]; ++r) fold_v<MODE>(acc[k], s[(size_t)r * cv + c[k]]);
         if (MODE == MVF_REDUCE_MEAN && b[k] > a[k]) scale_v(acc[k], (float)(b[k] - a[k]));
         const i64 e = e0 + k * 256;
         if (e < total) o[e] = acc[k];
