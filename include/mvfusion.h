@@ -261,6 +261,20 @@ int mvf_mlp_forward(
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, void *stream);
 
+/* The same chain with a dot-product epilogue: the last layer's output y
+ * [rows][cout <= 32] is not stored; instead
+ *   dot_out[r] = sum_c y[r][c] * queries[row2seg[r]][c]     (/ divisor when divisor != 0)
+ * i.e. keys = K(...) and compatibilities = (keys * queries).sum / sqrt(D) of
+ * QKVBimodalCSRPool.forward with one group (pooling.py:486-508) without the
+ * keys ever leaving the chip.  Products and sums are rounded one by one, the
+ * order of the sum differs from the reference's (within fp32 tolerance). */
+int mvf_mlp_forward_dot(
+    const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
+    const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
+    int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
+    const float *queries, int32_t ldq, const int32_t *row2seg, float divisor, float *dot_out,
+    void *stream);
+
 /* The attention tail shared by QKVBimodalCSRPool.forward (pooling.py:503-530)
  * and GroupBimodalCSRPool.forward (pooling.py:284-300):
  *   comp[r][g] = sum_k keys[r][g D + k] * queries[seg(r)][g D + k]   (/ sqrt(D) if dim_scaling)

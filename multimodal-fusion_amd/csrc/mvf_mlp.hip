@@ -62,6 +62,13 @@ struct MlpArgs {
     mvf_mlp_layer L[MLP_MAX_LAYERS];
     float *out;
     int ldo;
+    // dot epilogue (dot_out != null): instead of the last layer's output y [rows][cout <= 32],
+    // dot_out[row] = sum_c y[row][c] * dot_q[dot_seg[row]][c]  (/ dot_div when dot_div != 0)
+    const float *dot_q;
+    const int *dot_seg;
+    int dot_ldq;
+    float dot_div;
+    float *dot_out;
 };
 
 __host__ __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
@@ -331,6 +338,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         floatx16 acc0, acc1;
         mlp_init_acc(acc0, 0, sh, kh);
         mlp_init_acc(acc1, 1, sh, kh);
+        // dot epilogue: the row's query index now, its query values after the first
+        // layer, so that neither load is waited for at the end of the tile
+        const int qseg = (A.dot_out && live) ? A.dot_seg[row] : 0;
+        float qv[16];
 
         // ---- first layer: the lane's half of each 64-column chunk of its row ----
         for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -391,6 +402,18 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             }
             if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
+        if (A.dot_out) {
+            const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
+            const int cq = A.L[nlayers - 1].cout;
+            // 16-byte loads (the host checks alignment and cout % 4 == 0)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 4 * kh + 8 * g;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < cq) t = ld4(qrow + c);
+                qv[4 * g] = t.x; qv[4 * g + 1] = t.y; qv[4 * g + 2] = t.z; qv[4 * g + 3] = t.w;
+            }
+        }
         // ---- the following layers, activations stay in registers ----
         auto nothing = [](int) {};
 #pragma unroll
@@ -433,7 +456,24 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             acc0 = n0;
             acc1 = n1;
         }
-        {
+        if (A.dot_out) {
+            // The last layer's rows meet one query row each and only the products'
+            // sum leaves the kernel (the keys and compatibilities of the attentive
+            // pools, pooling.py:503-508).  A row's 32 channels sit in the two lanes
+            // jrow and jrow + 32.
+            const mvf_mlp_layer &L = A.L[nlayers - 1];
+            float part = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                mlp_epilogue4(acc0, g, L);
+                const int c = 4 * kh + 8 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < L.cout) part = __fadd_rn(part, __fmul_rn(acc0[4 * g + e], qv[4 * g + e]));
+            }
+            part = __fadd_rn(part, __shfl_xor(part, 32, 64));
+            if (live && kh == 0) A.dot_out[row] = A.dot_div != 0.f ? __fdiv_rn(part, A.dot_div) : part;
+        } else {
             // epilogue and store of the last layer
             const mvf_mlp_layer &L = A.L[nlayers - 1];
             const bool wide = cop_of(nlayers - 1) > 32;
@@ -676,17 +716,25 @@ extern "C" int mvf_debug_mlp_switch(int mask)
 }
 #endif
 
-extern "C" int mvf_mlp_forward(
+static int mlp_forward_impl(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    float *out, int32_t ldo, void *stream)
+    float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
+    float dot_div, float *dot_out, void *stream)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
     MVF_REQUIRE(mode >= 0 && mode <= 2, "mlp_forward: unknown input mode %d", mode);
     if (rows == 0) return MVF_OK;
-    MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && out, "mlp_forward: bad first input");
+    MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out), "mlp_forward: bad first input");
+    if (dot_out) {
+        MVF_REQUIRE(dot_q && dot_seg && layers[nlayers - 1].cout <= 32 && dot_ldq >= layers[nlayers - 1].cout,
+                    "mlp_forward_dot: needs query rows, the row -> query map and at most 32 output channels");
+        MVF_REQUIRE(layers[nlayers - 1].cout % 4 == 0 && dot_ldq % 4 == 0 && (uintptr_t)dot_q % 16 == 0,
+                    "mlp_forward_dot: query rows must be 16-byte aligned, with a multiple of 4 channels");
+        if (!out) { out = dot_out; ldo = layers[nlayers - 1].cout; }    // never written; keeps the checks below simple
+    }
     MVF_REQUIRE((mode == 0 && !xb) || (xb && cols_b >= 1 && ldb >= cols_b),
                 "mlp_forward: bad second input");
     MVF_REQUIRE(mode == 0 || cols_a == cols_b, "mlp_forward: summed inputs differ in width");
@@ -712,6 +760,7 @@ extern "C" int mvf_mlp_forward(
     for (int l = 0; l < nlayers; ++l) A.L[l] = layers[l];
     A.out = out;
     A.ldo = ldo;
+    A.dot_q = dot_q; A.dot_seg = dot_seg; A.dot_ldq = dot_ldq; A.dot_div = dot_div; A.dot_out = dot_out;
     A.debug = 0;
 #ifdef MVF_MLP_DEBUG
     A.debug = g_mlp_debug;
@@ -720,7 +769,7 @@ extern "C" int mvf_mlp_forward(
     const bool al_a = ((uintptr_t)xa % 16 == 0) && lda % 4 == 0;
     const bool al_b = !xb || (((uintptr_t)xb % 16 == 0) && ldb % 4 == 0);
     A.vec_in = al_a && al_b && cin0 % 8 == 0 && cols_a % 4 == 0;
-    A.vec_out = ((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0;
+    A.vec_out = dot_out || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
     const size_t lds = mlp_lds_bytes(layers, nlayers);
     static int cus = 0;
     if (cus == 0) {
@@ -767,6 +816,28 @@ extern "C" int mvf_mlp_forward(
 #undef MVF_MLP_LAUNCH
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_mlp_forward(
+    const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
+    const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
+    int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
+    float *out, int32_t ldo, void *stream)
+{
+    return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, mode, rows, layers,
+                            nlayers, out, ldo, nullptr, 0, nullptr, 0.f, nullptr, stream);
+}
+
+extern "C" int mvf_mlp_forward_dot(
+    const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
+    const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
+    int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
+    const float *queries, int32_t ldq, const int32_t *row2seg, float divisor, float *dot_out,
+    void *stream)
+{
+    MVF_REQUIRE(dot_out, "mlp_forward_dot: null output");
+    return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, mode, rows, layers,
+                            nlayers, nullptr, 0, queries, ldq, row2seg, divisor, dot_out, stream);
 }
 
 extern "C" int mvf_attention_pool(

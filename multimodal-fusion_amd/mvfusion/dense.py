@@ -86,10 +86,11 @@ def _check_eval(spec):
             "(train-mode batch statistics and backward are not implemented)")
 
 
-def _launch(src, specs, cols, out, ldo_tensor):
+def _launch(src, specs, cols, out, ldo_tensor, dot=None):
     """One mvf_mlp_forward launch.  src = (xa, ga, xb, gb, mode); specs = list
     of (LayerSpec, lo, hi); out = tensor view whose first element is the
-    output's first column, ldo_tensor = row stride in floats."""
+    output's first column, ldo_tensor = row stride in floats.  dot = (queries,
+    row2seg, divisor): mvf_mlp_forward_dot, `out` is the [rows] dot output."""
     lib = L.load()
     xa, ga, xb, gb, mode = src
     keep = []
@@ -110,19 +111,39 @@ def _launch(src, specs, cols, out, ldo_tensor):
     rows = xa.shape[0] if ga is None else ga.shape[0]
     dev = xa.device
     with torch.cuda.device(dev):
-        L.check(lib.mvf_mlp_forward(
-            L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
-            L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
-            L.ptr(gb), mode, rows, arr, len(specs), L.ptr(out), ldo_tensor,
-            L.stream_ptr(dev)))
+        if dot is None:
+            L.check(lib.mvf_mlp_forward(
+                L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
+                L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
+                L.ptr(gb), mode, rows, arr, len(specs), L.ptr(out), ldo_tensor,
+                L.stream_ptr(dev)))
+        else:
+            q, seg, div = dot
+            L.check(lib.mvf_mlp_forward_dot(
+                L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
+                L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
+                L.ptr(gb), mode, rows, arr, len(specs), L.ptr(q), q.stride(0), L.ptr(seg),
+                float(div), L.ptr(out), L.stream_ptr(dev)))
     del keep
 
 
-def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0):
+def dot_fusable(specs, queries):
+    """Can run_layers(..., dot=...) fold the last layer into its dot epilogue?"""
+    return (len(specs) >= 1 and specs[-1].cout <= 32 and specs[-1].cout % 4 == 0
+            and specs[-1].cin <= _MAX_C and queries.shape[1] == specs[-1].cout
+            and queries.stride(1) == 1 and queries.stride(0) % 4 == 0 and queries.data_ptr() % 16 == 0)
+
+
+def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0, dot=None):
     """y = specs[-1](... specs[0](input)) with input rows
     [xa[ga] | xb[gb]] (mode 0), xa + xb (mode 1) or [xa | xa + xb] (mode 2).
     Layers are packed into as few kernel launches as the width limits allow;
-    a layer wider than 64 outputs runs alone, 64 output columns per launch."""
+    a layer wider than 64 outputs runs alone, 64 output columns per launch.
+
+    dot = (queries [nq, cout], row2seg int32 [rows], divisor): y itself is not
+    returned; the result is [rows, 1] with sum_c y[r, c] * queries[row2seg[r], c]
+    (/ divisor when it is not 0), computed in the epilogue of the last launch
+    (needs dot_fusable)."""
     def prep(t):
         if t is None:
             return None
@@ -162,8 +183,16 @@ def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0):
                 group.append((specs[j], 0, specs[j].cout))
                 j += 1
             cout = group[-1][0].cout
-            out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
-            _launch(src, group, None, out, cout)
+            if dot is not None and j == len(specs):
+                q, seg, div = dot
+                q = prep(q)
+                if seg.dtype != torch.int32 or not seg.is_cuda or seg.shape[0] != rows:
+                    raise TypeError("row2seg must be an int32 device tensor with one entry per row")
+                out = torch.empty((rows, 1), dtype=torch.float32, device=dev)
+                _launch(src, group, None, out, 1, dot=(q, seg, div))
+            else:
+                out = torch.empty((rows, cout), dtype=torch.float32, device=dev)
+                _launch(src, group, None, out, cout)
             i = j
         x = out
         src = (x, None, None, None, 0)

@@ -315,7 +315,7 @@ class MinMaxDiffSetFeat(nn.Module, ABC):
         in_mlp = d_in * (1 + self.use_min + self.use_max) + self.use_num
         self.mlp = MLP([in_mlp, d_out, d_out], bias=False)
 
-    def embed(self, x, ptr, row2seg, tail=()):
+    def embed(self, x, ptr, row2seg, tail=(), dot=None):
         parts = [x]
         if self.use_min:
             parts.append(x - segment_gather_csr(x, ptr, reduce='min'))
@@ -325,7 +325,7 @@ class MinMaxDiffSetFeat(nn.Module, ABC):
             num = _set_num(ptr)
             parts.append(num.repeat_interleave(ptr[1:] - ptr[:-1]).view(-1, 1))
         x_out = torch.cat(parts, dim=1) if len(parts) > 1 else x
-        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x_out)
+        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x_out, dot=dot)
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
@@ -364,9 +364,10 @@ class DeepSetFeat(nn.Module, ABC):
         in_last_mlp = d_out if fusion == 'residual' else d_out * 2
         self.mlp_elt_2 = MLP([in_last_mlp, d_out, d_out], bias=False)
 
-    def embed(self, x, ptr, row2seg, tail=()):
+    def embed(self, x, ptr, row2seg, tail=(), dot=None):
         """forward with optional extra layers (the pools' K / E_score Linear)
-        fused behind mlp_elt_2."""
+        fused behind mlp_elt_2, and optionally their dot product with a query
+        row per element (run_layers' dot)."""
         if row2seg is None:
             row2seg = _dense.csr_row_segments(ptr, x.shape[0])
         x1 = _dense.run_layers(_dense.mlp_layers(self.mlp_elt_1), x)
@@ -378,7 +379,7 @@ class DeepSetFeat(nn.Module, ABC):
         mode = {'concatenation': 0, 'residual': 1, 'both': 2}[self.fusion]
         # gather_csr(x_set) and the fusion happen while mlp_elt_2 loads its input
         return _dense.run_layers(
-            _dense.mlp_layers(self.mlp_elt_2) + list(tail), x1, None, x_set, row2seg, mode)
+            _dense.mlp_layers(self.mlp_elt_2) + list(tail), x1, None, x_set, row2seg, mode, dot=dot)
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
@@ -398,8 +399,8 @@ class MLPSetFeat(nn.Module, ABC):
         self.d_out = d_out
         self.mlp = MLP([d_in, d_out, d_out], bias=False)
 
-    def embed(self, x, ptr, row2seg, tail=()):
-        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x)
+    def embed(self, x, ptr, row2seg, tail=(), dot=None):
+        return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x, dot=dot)
 
     def forward(self, x, csr_idx):
         return self.embed(x, None, None)
@@ -610,16 +611,6 @@ class QKVBimodalCSRPool(_AttentivePool):
         # values : V x F_mod
         x_mod = _dense.run_layers(_dense.mlp_layers(self.E_mod), x_mod)
 
-        # keys : V x (D x num_groups), the K Linear fused behind the map encoder
-        if self.use_mod_k or self.save_last:
-            x_map = self.E_map.embed(x_map, ptr, row2seg)
-            if self.use_mod_k:
-                keys = _dense.run_layers(_dense.mlp_layers(self.E_mix_K) + k_lin, x_map, None, x_mod)
-            else:
-                keys = _dense.run_layers(k_lin, x_map)
-        else:
-            keys = self.E_map.embed(x_map, ptr, row2seg, tail=k_lin)
-
         # queries : N x (D x num_groups), or V x ... when the modality is mixed in
         if self.use_mod_q:
             x_main = _dense.run_layers(_dense.mlp_layers(self.E_main), x_main)
@@ -628,8 +619,24 @@ class QKVBimodalCSRPool(_AttentivePool):
         else:
             queries = _dense.run_layers(_dense.mlp_layers(self.E_main) + q_lin, x_main)
 
+        # keys : V x (D x num_groups), the K Linear fused behind the map encoder.
+        # With one group and plain keys / queries the compatibilities come out of
+        # the same launch (the keys meet their query row in its epilogue).
+        keys = comp = None
+        if self.use_mod_k or self.save_last:
+            x_map = self.E_map.embed(x_map, ptr, row2seg)
+            if self.use_mod_k:
+                keys = _dense.run_layers(_dense.mlp_layers(self.E_mix_K) + k_lin, x_map, None, x_mod)
+            else:
+                keys = _dense.run_layers(k_lin, x_map)
+        elif self.num_groups == 1 and not self.use_mod_q and _dense.dot_fusable(k_lin, queries):
+            div = math.sqrt(self.nc_qk) if self.dim_scaling else 0.0
+            comp = self.E_map.embed(x_map, ptr, row2seg, tail=k_lin, dot=(queries, row2seg, div))
+        else:
+            keys = self.E_map.embed(x_map, ptr, row2seg, tail=k_lin)
+
         x_pool, comp, att, gate = _dense.attention_pool(
-            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), keys=keys,
+            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), keys=keys, comp=comp,
             queries=queries, row2seg=None if self.use_mod_q else row2seg, nc_qk=self.nc_qk,
             dim_scaling=self.dim_scaling, group_scaling=self.group_scaling,
             gate_w=None if self.G is None else self.G.weight,

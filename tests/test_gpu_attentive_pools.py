@@ -191,3 +191,28 @@ def test_training_mode_and_cpu_inputs_raise():
         mod.to(DEV)(x, x, x, torch.tensor([0, 1, 2], device=DEV))
     with pytest.raises(RuntimeError):
         mod.eval()(x.cpu(), x.cpu(), x.cpu(), torch.tensor([0, 1, 2]))
+
+
+def test_mlp_chain_dot_epilogue():
+    """run_layers(..., dot=...) == (run_layers(...) * queries[row2seg]).sum(1) / divisor
+    for one, two and three fused layers, ragged row counts and 8 / 16 / 32 keys."""
+    from mvfusion import dense
+    torch.manual_seed(5)
+    for rows, nq, chans, D in [(1000, 300, [8, 32, 32], 16), (4097, 1000, [64, 32, 32], 8),
+                               (33, 7, [24], 32), (70000, 20000, [40, 64], 16)]:
+        mlp = _random_module(pooling.MLP(chans, bias=False), 9).to(DEV).eval() if len(chans) > 1 else None
+        lin = torch.nn.Linear(chans[-1], D).to(DEV)
+        specs = (dense.mlp_layers(mlp) if mlp is not None else []) + [dense.linear_layer(lin)]
+        x = torch.rand((rows, chans[0]), device=DEV) - 0.5
+        q = torch.rand((nq, D), device=DEV) - 0.5
+        seg = torch.randint(0, nq, (rows,), device=DEV, dtype=torch.int32)
+        assert dense.dot_fusable(specs, q)
+        keys = dense.run_layers(specs, x)
+        for div in (0.0, 4.0):
+            got = dense.run_layers(specs, x, dot=(q, seg, div))
+            want = (keys.double() * q[seg.long()].double()).sum(1, keepdim=True)
+            if div:
+                want = want / div
+            assert got.shape == (rows, 1)
+            err = (got.double() - want).abs().max().item()
+            assert err <= 1e-5 * max(want.abs().max().item(), 1e-3), (rows, chans, D, err)
