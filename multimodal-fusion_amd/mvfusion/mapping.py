@@ -9,7 +9,7 @@ Layout (all on one device):
 """
 import torch
 
-from .csr import CSRData, CSRBatch
+from .csr import CSRData, CSRBatch, tensor_idx
 from . import pooling as _pooling
 
 
@@ -118,6 +118,65 @@ class ImageMapping(CSRData):
                                 is_index_value=[True, False])
         return ImageMapping(pointers, images, nested, features, dense=False,
                             is_index_value=[True, False, False])
+
+    def select_points(self, idx, mode='pick'):
+        """Update the 3D points sampling (core/multimodal/image.py:2177-2287):
+        'pick' keeps the points ``idx``; 'merge' agglomerates point i into point
+        ``idx[i]``, combining the mappings and dropping duplicate pixels (the
+        first row of each duplicate in (point, image, x, y) order keeps its
+        view-averaged features).  Returns a new ImageMapping."""
+        MODES = ['pick', 'merge']
+        assert mode in MODES, \
+            f"Unknown mode '{mode}'. Supported modes are {MODES}."
+        idx = tensor_idx(idx).to(self.device)
+        if idx is None or idx.shape[0] == 0 or self.num_groups == 0:
+            return self.clone()
+        if self.num_items == 0:
+            out = self.clone()
+            out.pointers = torch.zeros(idx.shape[0] + 1, dtype=torch.int64, device=self.device)
+            return out
+        if mode == 'pick':
+            return self[idx]
+
+        if not idx.shape[0] == self.num_groups > 0:
+            return self.clone()
+        if not torch.arange(int(idx.max()) + 1, device=self.device).equal(idx.unique()):
+            return self.clone()
+
+        # dense view-level format
+        view_sizes = self.pointers[1:] - self.pointers[:-1]
+        point_ids = idx.repeat_interleave(view_sizes)
+        image_ids = self.images
+        if not self.has_features:
+            features = None
+        elif self.num_items <= 1:
+            features = self.features
+        else:
+            # mean of the features of all views that land on the same (point,
+            # image) pair, redistributed to the source views; rows are summed in
+            # their input order (a stable sort feeds the segment kernel)
+            view_ids = composite_key(point_ids, image_ids)
+            order = torch.sort(view_ids, stable=True).indices
+            ks = view_ids[order]
+            first = torch.ones_like(ks, dtype=torch.bool)
+            first[1:] = ks[1:] != ks[:-1]
+            starts = torch.where(first)[0]
+            ptr = torch.cat([starts, torch.tensor([ks.shape[0]], device=ks.device)])
+            mean = _pooling.segment_csr(self.features.float()[order].contiguous(), ptr, reduce='mean')
+            group = torch.cumsum(first.to(torch.int64), 0) - 1
+            features = torch.empty_like(mean[group])
+            features[order] = mean[group]
+        # dense atomic-level format
+        pixel_sizes = self.values[1].pointers[1:] - self.values[1].pointers[:-1]
+        point_ids = point_ids.repeat_interleave(pixel_sizes)
+        image_ids = image_ids.repeat_interleave(pixel_sizes)
+        if features is not None:
+            features = features.repeat_interleave(pixel_sizes, dim=0)
+        pixels = self.pixels
+        keep = lexargunique(point_ids, image_ids, pixels[:, 0], pixels[:, 1])
+        return ImageMapping.from_dense(
+            point_ids[keep], image_ids[keep], pixels[keep],
+            features[keep] if features is not None else None, num_points=int(idx.max()) + 1)
 
     def debug(self):
         super(ImageMapping, self).debug()

@@ -508,6 +508,39 @@ def mapping_from_dense(point_ids, image_ids, pixels, features, num_points=None):
 # core/data_transform/multimodal/image.py :: MapImages._process               #
 # --------------------------------------------------------------------------- #
 
+def select_points(m, idx, mode="pick"):
+    """ImageMapping.select_points, core/multimodal/image.py:2177-2287, on a
+    mapping dict as returned by mapping_from_dense (with features)."""
+    idx = np.asarray(idx, np.int64)
+    ptr, vptr = m["pointers"], m["view_pointers"]
+    if mode == "pick":
+        # CSRData.__getitem__, csr.py:235-294
+        views = np.concatenate([np.arange(ptr[i], ptr[i + 1]) for i in idx] + [np.zeros(0, np.int64)]).astype(np.int64)
+        px = np.concatenate([np.arange(vptr[v], vptr[v + 1]) for v in views] + [np.zeros(0, np.int64)]).astype(np.int64)
+        return dict(
+            pointers=np.concatenate([[0], np.cumsum(ptr[idx + 1] - ptr[idx])]).astype(np.int64),
+            images=m["images"][views],
+            view_pointers=np.concatenate([[0], np.cumsum(vptr[views + 1] - vptr[views])]).astype(np.int64),
+            pixels=m["pixels"][px], features=m["features"][views])
+    assert mode == "merge" and idx.shape[0] == ptr.shape[0] - 1
+    point_ids = np.repeat(idx, np.diff(ptr))
+    image_ids = m["images"]
+    key = composite(point_ids, image_ids)
+    feats = m["features"]
+    mean = np.zeros_like(feats)
+    for k in np.unique(key):                       # scatter_mean + gather, rows in input order
+        rows = np.where(key == k)[0]
+        acc = feats[rows[0]].copy()
+        for r in rows[1:]:
+            acc = acc + feats[r]
+        mean[rows] = acc / np.float32(len(rows))
+    sizes = np.diff(vptr)
+    point_ids, image_ids, mean = np.repeat(point_ids, sizes), np.repeat(image_ids, sizes), np.repeat(mean, sizes, axis=0)
+    pix = m["pixels"]
+    u = lexargunique(point_ids, image_ids, pix[:, 0], pix[:, 1])
+    return mapping_from_dense(point_ids[u], image_ids[u], pix[u], mean[u], num_points=int(idx.max()) + 1)
+
+
 def pixel_dtype(ref_size):
     """SameSettingImageData.pixel_dtype, core/multimodal/image.py:507-516."""
     for dt in (np.int16, np.int32, np.int64):

@@ -71,6 +71,19 @@ def segment_csr(src, indptr, out=None, reduce="sum"):
     return res
 
 
+def scatter_mean(src, index, dim=0, dim_size=None):
+    """torch_scatter.scatter_mean on dim 0: out[j] = mean of src[index == j]
+    (0 where no row maps to j), rows added in input order."""
+    assert dim == 0
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    cnt = torch.zeros(n, dtype=src.dtype)
+    out.index_add_(0, index, src)
+    cnt.index_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype))
+    cnt = cnt.clamp(min=1)
+    return out / cnt.view((-1,) + (1,) * (src.dim() - 1))
+
+
 def _scatter_minmax(src, index, dim=0, dim_size=None, is_min=True):
     n = int(index.max()) + 1 if dim_size is None else dim_size
     if src.dim() == 1:
@@ -181,7 +194,7 @@ def load_reference():
     if _loaded:
         return _loaded
     _mod("numba", njit=_njit)
-    _mod("torch_scatter", segment_csr=segment_csr,
+    _mod("torch_scatter", segment_csr=segment_csr, scatter_mean=scatter_mean,
          scatter_min=lambda s, i, dim=0, dim_size=None: _scatter_minmax(s, i, dim, dim_size, True),
          scatter_max=lambda s, i, dim=0, dim_size=None: _scatter_minmax(s, i, dim, dim_size, False))
     _mod("pykeops")

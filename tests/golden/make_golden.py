@@ -292,6 +292,33 @@ def gen_from_dense():
          **arrs)
 
 
+# ------------------------------------------------------------- select_points
+def gen_select_points():
+    """ImageMapping.select_points (core/multimodal/image.py:2177-2287), the CSR
+    re-indexing after a 3D sampling ('pick') or a strided convolution ('merge')."""
+    image = ref["image"]
+    rng = np.random.default_rng(21)
+    P, n_pts, n_img = 3000, 400, 5
+    pid = rng.integers(0, n_pts - 30, P)
+    iid = rng.integers(0, n_img, P)
+    pix = rng.integers(0, 40, (P, 2)).astype(np.int16)      # small images: duplicates after merging
+    feat = rng.random((P, 3)).astype(np.float32)
+    m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
+    pick = rng.permutation(n_pts)[:150].astype(np.int64)
+    out_pick = m.select_points(T(pick), mode='pick')
+    n_vox = 120
+    merge = np.concatenate([np.arange(n_vox), rng.integers(0, n_vox, n_pts - n_vox)]).astype(np.int64)
+    merge = merge[rng.permutation(n_pts)]
+    out_merge = m.select_points(T(merge), mode='merge')
+    arrs = dict(point_ids=pid, image_ids=iid, pixels=pix, features=feat, num_points=n_pts,
+                pick=pick, merge=merge)
+    for tag, o in (("pick", out_pick), ("merge", out_merge)):
+        arrs.update({tag + "_pointers": o.pointers.numpy(), tag + "_images": o.images.numpy(),
+                     tag + "_view_pointers": o.values[1].pointers.numpy(),
+                     tag + "_pixels": o.pixels.numpy(), tag + "_features": o.features.numpy()})
+    save("select_points", **arrs)
+
+
 # ------------------------------------------------------------------- pooling
 def random_ptr(rng, nseg, mean, long_at=None):
     sizes = rng.poisson(mean, nseg)
@@ -465,6 +492,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "pooling", "attention_pools", "attention_variants"]
+        "from_dense", "select_points", "pooling", "attention_pools", "attention_variants"]
     for w in which:
         globals()["gen_" + w]()

@@ -137,3 +137,27 @@ def test_segment_csr_two_level_equals_two_passes(inner):
                     assert np.array_equal(N(g_), want)
                 else:
                     np.testing.assert_allclose(N(g_), want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["pick", "merge"])
+def test_select_points_golden(golden, mode):
+    """ImageMapping.select_points (core/multimodal/image.py:2177-2287) against
+    the reference's output: CSR arrays bit-exact, features to 1e-6."""
+    g = golden("select_points")
+    m = M.ImageMapping.from_dense(
+        T(g["point_ids"]), T(g["image_ids"]), T(g["pixels"]), T(g["features"]),
+        num_points=int(g["num_points"]))
+    out = m.select_points(T(g[mode]), mode=mode)
+    assert isinstance(out, M.ImageMapping)
+    assert np.array_equal(N(out.pointers), g[mode + "_pointers"])
+    assert np.array_equal(N(out.images), g[mode + "_images"])
+    vp = g[mode + "_view_pointers"]
+    assert np.array_equal(N(out.atomic_csr_indexing), vp)
+    assert np.array_equal(canonical_pixels(vp, N(out.pixels)), canonical_pixels(vp, g[mode + "_pixels"]))
+    np.testing.assert_allclose(N(out.features), g[mode + "_features"], rtol=1e-6, atol=1e-7)
+    # degenerate inputs return an unchanged copy / empty groups (image.py:2208-2215)
+    same = m.select_points(T(np.zeros(0, np.int64)), mode=mode)
+    assert torch.equal(same.pointers, m.pointers)
+    if mode == "merge":
+        bad = m.select_points(T(g["merge"][:-1]), mode="merge")      # wrong length: unchanged
+        assert torch.equal(bad.pointers, m.pointers)

@@ -112,6 +112,21 @@ def test_from_dense(golden):
     np.testing.assert_allclose(m["features"], g["out_features"], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("mode", ["pick", "merge"])
+def test_select_points(golden, mode):
+    g = golden("select_points")
+    m = orc.mapping_from_dense(
+        g["point_ids"], g["image_ids"], g["pixels"], g["features"],
+        num_points=int(g["num_points"]))
+    out = orc.select_points(m, g[mode], mode)
+    assert np.array_equal(out["pointers"], g[mode + "_pointers"])
+    assert np.array_equal(out["images"], g[mode + "_images"])
+    assert np.array_equal(out["view_pointers"], g[mode + "_view_pointers"])
+    vp = g[mode + "_view_pointers"]
+    assert np.array_equal(canonical_pixels(vp, out["pixels"]), canonical_pixels(vp, g[mode + "_pixels"]))
+    np.testing.assert_allclose(out["features"], g[mode + "_features"], rtol=1e-6, atol=1e-7)
+
+
 def _cams(g):
     return dict(pos=g["cam_pos"], extrinsic=g["extrinsic"], fx=g["fx"], fy=g["fy"],
                 mx=g["mx"], my=g["my"])
