@@ -120,3 +120,21 @@ def test_c4_batch_of_cylinders():
     x_view = gather_atomic_pool(x_all, batch, "max")
     x_point = BimodalCSRPool(mode="max")(None, x_view, None, batch.view_csr_indexing)
     assert np.array_equal(npy(x_point), np.concatenate(refs, 0))
+
+
+@pytest.mark.parametrize("n_views", [33, 70])
+def test_fused_map_images_many_views(n_views):
+    """More views than one 32-bit word of the per-point view masks / one 64-byte
+    row of seen flags: fused exact MapImages against the oracle."""
+    from mvfusion.transforms import MapImages, kdtree_order
+    sc = S.make_scene("c1", seed=40 + n_views, n_points=20000, n_views=n_views)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    order = kdtree_order(T(xyz), True).numpy()
+    data, images = make_inputs(xyz, np.arange(N), sc, sc["img_size"], attrs=True, order=order)
+    nrm, lin, pla, sca = S.surface_normals(xyz)
+    ref = orc.map_images(xyz, np.arange(N), sc, order=order, ref_size=sc["img_size"], cylinder=True,
+                         exact=True, linearity=lin, planarity=pla, scattering=sca, normals=nrm, **VIS)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+    _, out = t(data, images)
+    check_mapping(out.mappings, ref)
