@@ -138,3 +138,54 @@ def test_fused_map_images_many_views(n_views):
     t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
     _, out = t(data, images)
     check_mapping(out.mappings, ref)
+
+
+@pytest.mark.parametrize("case", ["scannet", "mask_crop_rmin", "upscale_downscale_crop", "sphere"])
+def test_fused_map_images_options(case):
+    """Option combinations of the fused exact path against the oracle on a small
+    scene: world-to-camera extrinsics ('scannet'), image mask + crop_top /
+    crop_bottom + r_min, proj_upscale / downscale / per-view crop offsets, and
+    spherical instead of cylindrical sampling."""
+    from mvfusion.images import SameSettingImageData
+    from mvfusion.transforms import MapImages, kdtree_order
+    sc = S.make_scene("c1", seed=77, n_points=30000, n_views=5)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    W, H = sc["img_size"]
+    vis = dict(VIS)
+    kw_img, kw_orc, cylinder, mask = {}, {}, True, None
+    extr = sc["extrinsic"]
+    if case == "scannet":
+        vis["camera"] = "scannet"
+        extr = np.stack([np.linalg.inv(e.astype(np.float64)).astype(np.float32) for e in extr])
+    elif case == "mask_crop_rmin":
+        rng = np.random.default_rng(1)
+        mask = rng.random((W, H)) > 0.3
+        vis.update(r_min=2.0, crop_top=40, crop_bottom=25)
+    elif case == "upscale_downscale_crop":
+        ref_size = (W // 2, H // 2)
+        offs = np.array([[10 * k, 3 * k] for k in range(5)], np.int64)
+        kw_img = dict(proj_upscale=2, downscale=2, crop_size=(ref_size[0] - 64, ref_size[1] - 16),
+                      crop_offsets=T(offs))
+        kw_orc = dict(proj_upscale=2, downscale=2, crop_size=(ref_size[0] - 64, ref_size[1] - 16),
+                      crop_offsets=offs)
+    elif case == "sphere":
+        cylinder = False
+        vis["r_max"] = 5
+    ref_size = (W // 2, H // 2) if case == "upscale_downscale_crop" else (W, H)
+    cams = dict(sc, extrinsic=extr)
+    order = kdtree_order(T(xyz), cylinder).numpy()
+    ref = orc.map_images(xyz, np.arange(N), cams, order=order, ref_size=ref_size, cylinder=cylinder,
+                         img_mask=mask, exact=True, **kw_orc, **vis)
+    data = Data()
+    data.pos = T(xyz)
+    data.mapping_index = torch.arange(N)
+    data.mvf_point_order = T(order)
+    images = SameSettingImageData(
+        pos=T(sc["pos"]), extrinsic=T(extr), fx=T(sc["fx"]), fy=T(sc["fy"]), mx=T(sc["mx"]),
+        my=T(sc["my"]), ref_size=ref_size, mask=None if mask is None else T(mask),
+        **(kw_img or dict(proj_upscale=1)))
+    t = MapImages(method="SplattingVisibility", cylinder=cylinder, exact=True, **vis)
+    _, out = t(data, images)
+    assert out.mappings.pointers.shape[0] == N + 1 and ref["images"].shape[0] > 500
+    check_mapping(out.mappings, ref)
