@@ -189,3 +189,21 @@ def test_fused_map_images_options(case):
     _, out = t(data, images)
     assert out.mappings.pointers.shape[0] == N + 1 and ref["images"].shape[0] > 500
     check_mapping(out.mappings, ref)
+
+
+def test_map_images_repeated_mapping_ids():
+    """Several points share a mapping id (voxelised clouds): several pixels per
+    (id, view) group, the path that cannot use the fused kernels."""
+    from mvfusion.transforms import MapImages, kdtree_order
+    sc = S.make_scene("c1", seed=78, n_points=20000, n_views=3)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    ids = np.arange(N) // 3
+    order = kdtree_order(T(xyz), True).numpy()
+    ref = orc.map_images(xyz, ids, sc, order=order, ref_size=sc["img_size"], cylinder=True,
+                         exact=True, **VIS)
+    data, images = make_inputs(xyz, ids, sc, sc["img_size"], attrs=False, order=order)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+    _, out = t(data, images)
+    assert np.diff(ref["view_pointers"]).max() > 1
+    check_mapping(out.mappings, ref)
