@@ -207,3 +207,20 @@ def test_map_images_repeated_mapping_ids():
     _, out = t(data, images)
     assert np.diff(ref["view_pointers"]).max() > 1
     check_mapping(out.mappings, ref)
+
+
+def test_c2_non_exact_splat_visibility_full_size():
+    """The WildScenes-shaped scan with exact=False (plain splat visibility: every
+    pixel a point wins is a mapping) through MapImages, against the oracle."""
+    from mvfusion.transforms import MapImages
+    sc = S.make_scene("c2", seed=2, n_views=4)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    assert N == 300_000
+    ref = orc.map_images(xyz, np.arange(N), sc, order=None, ref_size=sc["img_size"], cylinder=True,
+                         exact=False, **VIS)
+    data, images = make_inputs(xyz, np.arange(N), sc, sc["img_size"], attrs=False)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=False, point_order="index", **VIS)
+    _, out = t(data, images)
+    assert ref["pixels"].shape[0] > 1_000_000
+    check_mapping(out.mappings, ref)
