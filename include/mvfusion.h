@@ -40,12 +40,23 @@ enum {
     MVF_E_LAUNCH = -3      /* HIP launch / runtime error */
 };
 
-enum { MVF_CAM_KITTI360_PERSPECTIVE = 0, MVF_CAM_SCANNET = 1 };
+enum {
+    MVF_CAM_KITTI360_PERSPECTIVE = 0,
+    MVF_CAM_SCANNET = 1,
+    MVF_CAM_KITTI360_FISHEYE = 2,
+    MVF_CAM_S3DIS_EQUIRECTANGULAR = 3
+};
 enum { MVF_REDUCE_SUM = 0, MVF_REDUCE_MEAN = 1, MVF_REDUCE_MIN = 2, MVF_REDUCE_MAX = 3 };
 
-/* One pinhole view.  cam_to_world is the 4x4 extrinsic for
+/* One view.  Pinhole cameras: cam_to_world is the 4x4 extrinsic for
  * 'kitti360_perspective' and inverse(extrinsic) for 'scannet'
- * (core/multimodal/visibility.py:232-242). */
+ * (core/multimodal/visibility.py:232-242).
+ * 'kitti360_fisheye' (visibility.py:288-339): cam_to_world rows 0-2 hold the
+ * extrinsic, its unused last row holds xi, k1, k2 in [12], [13], [14];
+ * fx, fy, cx, cy hold gamma1, gamma2, u0, v0.
+ * 's3dis_equirectangular' (visibility.py:150-182): cam_to_world[0..8] is the
+ * row-major 3x3 rotation of pose_to_rotation_matrix_cpu(img_opk) (:57-90),
+ * computed on the host; fx..cy are unused. */
 typedef struct {
     float img_xyz[3];        /* camera centre used for the range test */
     float fx, fy, cx, cy;    /* intrinsic [0][0], [1][1], [0][2], [1][2] */
@@ -82,7 +93,7 @@ int mvf_profile_enable(int enable);
 int mvf_profile_read(float *h_ms, const char **h_names, int capacity);
 
 /* ---------------------------------------------------------------------- *
- * camera_projection  (visibility.py:478-538,592-623; pinhole cameras)
+ * camera_projection  (visibility.py:478-538,592-623; all four cameras)
  * Keeps points with r_min < dist < r_max that project inside the (cropped)
  * image, in front of the camera, on a true mask pixel; outputs are compacted
  * in ascending point index.  Outputs need room for n entries.
@@ -113,6 +124,19 @@ int mvf_splat_visibility(
     float fx, float fy, const mvf_vis_params *h_params, int64_t pair_capacity,
     int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same for any camera of h_params->camera (visibility.py:1115-1132): the
+ * splat boxes follow pinhole_splat_cpu (:761-827, fx / fy of h_view),
+ * equirectangular_splat_cpu (:630-704, image size only) or fisheye_splat_cpu
+ * (:876-953), which projects xyz[i] + (0, 0, swell * voxel / 2) again and
+ * therefore needs the world coordinates xyz [m][3] of the splats; xyz may be
+ * NULL for the other cameras.  Workspace as for mvf_splat_visibility. */
+int mvf_splat_visibility_view(
+    const double *x_proj, const double *y_proj, const float *dist, const float *xyz,
+    int64_t m, const mvf_view *h_view, const mvf_vis_params *h_params,
+    int64_t pair_capacity, int64_t *out_idx, int64_t *out_x, int64_t *out_y,
+    int64_t out_capacity, int64_t *counters, void *workspace, size_t workspace_bytes,
+    void *stream);
 
 /* ---------------------------------------------------------------------- *
  * visibility_from_depth_map  (visibility.py:1361-1388) on a decoded [W][H]

@@ -25,7 +25,7 @@ struct ProjPred {
     const float *xyz; mvf_view view; mvf_vis_params P; const uint8_t *mask;
     __device__ bool operator()(i64 i) const {
         Proj pr;
-        return project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
+        return project_point<true>(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
     }
 };
 struct ProjEmit {
@@ -33,32 +33,39 @@ struct ProjEmit {
     i64 *indices; float *dist; double *x; double *y;
     __device__ void operator()(i64 i, i64 pos) const {
         Proj pr;
-        project_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
-        indices[pos] = i; dist[pos] = pr.dist; x[pos] = (double)pr.x; y[pos] = (double)pr.y;
+        project_point<true>(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], view, P, mask, pr);
+        indices[pos] = i; dist[pos] = pr.dist; x[pos] = pr.x; y[pos] = pr.y;
     }
 };
 
 // ------------------------------------------------------------------------- //
-// splat sources: where a kernel gets (x, y, dist, fx, fy) of splat i, view v  //
+// splat sources: where a kernel gets (x, y, dist, sx, sy) of splat i, view v  //
 // ------------------------------------------------------------------------- //
-struct ArraySrc {                      // visibility_from_splatting(x_proj, y_proj, dist)
-    const double *x, *y; const float *dist; float fx, fy; i64 m;
+// (sx, sy) is the camera-specific input of splat_bbox.
+struct ArraySrc {                      // visibility_from_splatting(x_proj, y_proj, dist, xyz)
+    const double *x, *y; const float *dist; const float *xyz; mvf_view view; i64 m;
+    static constexpr bool ANY = true;
     __device__ i64 count() const { return m; }
-    __device__ bool get(i64 i, int, const mvf_vis_params &, double &ox, double &oy, float &od,
-                        float &ofx, float &ofy) const {
-        ox = x[i]; oy = y[i]; od = dist[i]; ofx = fx; ofy = fy; return true;
+    __device__ bool get(i64 i, int, const mvf_vis_params &P, double &ox, double &oy, float &od,
+                        double &sx, double &sy) const {
+        ox = x[i]; oy = y[i]; od = dist[i];
+        if (P.camera == MVF_CAM_KITTI360_FISHEYE)
+            sx = sy = fisheye_splat_width(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], ox, oy, view, P);
+        else { sx = (double)view.fx; sy = (double)view.fy; }
+        return true;
     }
 };
 
 struct CloudSrc {                      // fused MapImages: project xyz[i] into view v
     const float *xyz; const mvf_view *views; const uint8_t *mask; i64 n; int cylinder;
+    static constexpr bool ANY = false;     // pinhole cameras only
     __device__ i64 count() const { return n; }
     __device__ bool get(i64 i, int v, const mvf_vis_params &P, double &ox, double &oy, float &od,
-                        float &ofx, float &ofy) const {
+                        double &sx, double &sy) const {
         const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
         const mvf_view &view = views[v];
         Proj pr;
-        if (!project_point(px, py, pz, view, P, mask, pr)) return false;
+        if (!project_point<false>(px, py, pz, view, P, mask, pr)) return false;
         // radius sampling of MapImages (image.py:242-245; transforms.py:332,386):
         // float64 squared distance to the view centre <= r_max^2 (tested last: it
         // only removes points, and few reach it)
@@ -66,7 +73,7 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
         double d2 = ex * ex + ey * ey;
         if (!cylinder) { const double ez = (double)pz - view.centre[2]; d2 = d2 + ez * ez; }
         if (!(d2 <= P.r_max * P.r_max)) return false;
-        ox = (double)pr.x; oy = (double)pr.y; od = pr.dist; ofx = view.fx; ofy = view.fy;
+        ox = pr.x; oy = pr.y; od = pr.dist; sx = (double)view.fx; sy = (double)view.fy;
         return true;
     }
 };
@@ -179,10 +186,10 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
         uint4 *row = (uint4 *)(seen + (size_t)i * seen_stride);
         for (int k = 0; k < (int)(seen_stride >> 4); ++k) row[k] = make_uint4(0u, 0u, 0u, 0u);
     }
-    double x, y; float d = 0.f, fx, fy;
-    const bool have = live && src.get(i, v, P, x, y, d, fx, fy);
+    double x, y, sx, sy; float d = 0.f;
+    const bool have = live && src.get(i, v, P, x, y, d, sx, sy);
     BBox b{0, 0, 0, 0};
-    if (have) b = splat_bbox(x, y, d, fx, fy, P);
+    if (have) b = splat_bbox<Src::ANY>(x, y, d, sx, sy, P);
     const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
     const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
     const int ncnt = tiles_per_view * NCLS;
@@ -808,7 +815,7 @@ __global__ __launch_bounds__(256) void mi_centre_kernel(
         while (m) {
             const int v = 16 * chunk + __ffs(m) - 1;
             m &= m - 1;
-            double x, y; float d, fx, fy;
+            double x, y, fx, fy; float d;
             if (!src.get(i, v, P, x, y, d, fx, fy)) continue;
             const int cx = (int)x, cy = (int)y - P.crop_top;
             atomicMax(&centre_ws[((size_t)v * P.W + cx) * Hc + cy], ((u64)epoch << 32) | (u64)((unsigned)i + 1u));
@@ -827,7 +834,7 @@ __device__ __forceinline__ int mi_survives(
     const u64 *centre_ws, unsigned epoch, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
-    double x, y; float fx, fy;
+    double x, y, fx, fy;
     if (!src.get(i, v, P, x, y, dist, fx, fy)) return 0;
     const int cx = (int)x, cy = (int)y;
     const u64 want = ((u64)epoch << 32) | (u64)((unsigned)i + 1u);
@@ -847,7 +854,7 @@ __device__ __forceinline__ void mi_pixel(
     const CloudSrc &src, const mvf_vis_params &P, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
-    double x, y; float fx, fy;
+    double x, y, fx, fy;
     src.get(i, v, P, x, y, dist, fx, fy);
     px = ((int)x / X.up - src.views[v].crop_off_x) / X.down;
     py = ((int)y / X.up - src.views[v].crop_off_y) / X.down;
@@ -970,7 +977,7 @@ static int check_params(const mvf_vis_params *P, const char *who)
                 "%s: image size %dx%d out of range", who, P->W, P->H);
     MVF_REQUIRE(P->crop_top >= 0 && P->crop_bottom >= 0 && P->crop_top + P->crop_bottom < P->H,
                 "%s: crops %d+%d do not fit height %d", who, P->crop_top, P->crop_bottom, P->H);
-    MVF_REQUIRE(P->camera == MVF_CAM_KITTI360_PERSPECTIVE || P->camera == MVF_CAM_SCANNET,
+    MVF_REQUIRE(P->camera >= MVF_CAM_KITTI360_PERSPECTIVE && P->camera <= MVF_CAM_S3DIS_EQUIRECTANGULAR,
                 "%s: unknown camera %d", who, P->camera);
     return MVF_OK;
 }
@@ -1049,9 +1056,9 @@ extern "C" size_t mvf_splat_visibility_workspace_bytes(
     return b;
 }
 
-extern "C" int mvf_splat_visibility(
-    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
-    float fx, float fy, const mvf_vis_params *h_params, int64_t pair_capacity,
+static int splat_visibility_impl(
+    const double *x_proj, const double *y_proj, const float *dist, const float *xyz, int64_t m,
+    const mvf_view &view, const mvf_vis_params *h_params, int64_t pair_capacity,
     int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -1060,6 +1067,8 @@ extern "C" int mvf_splat_visibility(
     MVF_REQUIRE(x_proj && y_proj && dist && out_idx && out_x && out_y && counters,
                 "splat_visibility: null buffer");
     MVF_REQUIRE(pair_capacity >= 1 && out_capacity >= 0, "splat_visibility: bad capacity");
+    MVF_REQUIRE(xyz || h_params->camera != MVF_CAM_KITTI360_FISHEYE,
+                "splat_visibility: the fisheye splat needs xyz");
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     int tiles_x, tiles_y, Hc;
@@ -1089,7 +1098,7 @@ extern "C" int mvf_splat_visibility(
     if (P.exact) MVF_HIP(hipMemsetAsync(seen, 0, (size_t)m, st));
     MVF_HIP(hipMemsetAsync(idmap, 0, (size_t)npix * sizeof(unsigned), st));
 
-    ArraySrc src{x_proj, y_proj, dist, fx, fy, (i64)m};
+    ArraySrc src{x_proj, y_proj, dist, xyz, view, (i64)m};
     dim3 grid_m(cdiv(m, 256), 1), block(256);
     hipLaunchKernelGGL((bin_count_kernel<ArraySrc, false, BIN_LDS_WIDE>), grid_m, block, 0, st, src, P, tiles_y,
                        (int)tiles, tile_count, (uint8_t *)nullptr, (i64)0, (i64 *)nullptr, (int *)nullptr, 0,
@@ -1115,6 +1124,34 @@ extern "C" int mvf_splat_visibility(
     compact(pred, emit, npix, cblocks, (i64 *)counters, (i64)out_capacity, (i64 *)counters + 2, st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_splat_visibility(
+    const double *x_proj, const double *y_proj, const float *dist, int64_t m,
+    float fx, float fy, const mvf_vis_params *h_params, int64_t pair_capacity,
+    int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MVF_REQUIRE(h_params && (h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE ||
+                             h_params->camera == MVF_CAM_SCANNET),
+                "splat_visibility: pinhole cameras only (use mvf_splat_visibility_view)");
+    mvf_view view = {};
+    view.fx = fx; view.fy = fy;
+    return splat_visibility_impl(x_proj, y_proj, dist, nullptr, m, view, h_params, pair_capacity,
+                                 out_idx, out_x, out_y, out_capacity, counters, workspace,
+                                 workspace_bytes, stream);
+}
+
+extern "C" int mvf_splat_visibility_view(
+    const double *x_proj, const double *y_proj, const float *dist, const float *xyz, int64_t m,
+    const mvf_view *h_view, const mvf_vis_params *h_params, int64_t pair_capacity,
+    int64_t *out_idx, int64_t *out_x, int64_t *out_y, int64_t out_capacity,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MVF_REQUIRE(h_view != nullptr, "splat_visibility_view: null view");
+    return splat_visibility_impl(x_proj, y_proj, dist, xyz, m, *h_view, h_params, pair_capacity,
+                                 out_idx, out_x, out_y, out_capacity, counters, workspace,
+                                 workspace_bytes, stream);
 }
 
 extern "C" size_t mvf_depth_map_visibility_workspace_bytes(int64_t m)
@@ -1203,6 +1240,8 @@ extern "C" int mvf_map_images_exact(
     MVF_REQUIRE(epoch >= 1 && proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 &&
                 pair_capacity >= 1 && out_capacity >= 0, "map_images_exact: bad scalar argument");
     MVF_REQUIRE(h_params->exact, "map_images_exact: params.exact must be set");
+    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
+                "map_images_exact: pinhole cameras only");
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     int tiles_x, tiles_y, Hc;

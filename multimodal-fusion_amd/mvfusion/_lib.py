@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libmvfusion.so")
 
-CAMERAS = {"kitti360_perspective": 0, "scannet": 1}
+CAMERAS = {"kitti360_perspective": 0, "scannet": 1, "kitti360_fisheye": 2,
+           "s3dis_equirectangular": 3}
 REDUCE = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 
 
@@ -68,6 +69,8 @@ _SIGNATURES = {
     "mvf_splat_visibility_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I64]),
     "mvf_splat_visibility": (C.c_int, [_P, _P, _P, _I64, _F, _F, _P, _I64, _P, _P, _P, _I64,
                                        _P, _P, _SZ, _P]),
+    "mvf_splat_visibility_view": (C.c_int, [_P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P, _I64,
+                                            _P, _P, _SZ, _P]),
     "mvf_depth_map_visibility_workspace_bytes": (_SZ, [_I64]),
     "mvf_depth_map_visibility": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _F, _P, _P, _P,
                                            _P, _P, _SZ, _P]),

@@ -1,7 +1,8 @@
 """Minimal ``SameSettingImageData``: the per-sample holder of camera poses,
 intrinsics and image-state scalars that ``MapImages`` reads and annotates
 (subset of ``torch_points3d/core/multimodal/image.py:177-1297`` needed by the
-mapping path: pinhole cameras with 4x4 extrinsics; no image loading).
+mapping path: pinhole / fisheye cameras with 4x4 extrinsics, equirectangular
+cameras with omega-phi-kappa poses; no image loading).
 
 ``MapImages`` is duck-typed: any object exposing these attributes works,
 including the reference's own class.
@@ -20,8 +21,13 @@ class SameSettingImageData:
     def __init__(self, path=None, pos=torch.empty([0, 3]), extrinsic=None,
                  fx=None, fy=None, mx=None, my=None, ref_size=(512, 256),
                  proj_upscale=2, downscale=1, crop_size=None, crop_offsets=None,
-                 x=None, mappings=None, mask=None, visibility=None, **kwargs):
+                 x=None, mappings=None, mask=None, visibility=None, opk=None,
+                 xi=None, k1=None, k2=None, gamma1=None, gamma2=None, u0=None, v0=None,
+                 **kwargs):
         self.pos = pos.double()
+        self.opk = opk.double() if opk is not None else None
+        self.xi, self.k1, self.k2 = xi, k1, k2
+        self.gamma1, self.gamma2, self.u0, self.v0 = gamma1, gamma2, u0, v0
         n = self.pos.shape[0]
         self.path = np.array([f"view_{i}" for i in range(n)], dtype='O') \
             if path is None else np.array(path)
@@ -47,9 +53,11 @@ class SameSettingImageData:
     def device(self):
         return self.pos.device
 
+    _fisheye_keys = ('xi', 'k1', 'k2', 'gamma1', 'gamma2', 'u0', 'v0')
+
     @property
     def has_opk(self):
-        return False
+        return self.opk is not None
 
     @property
     def has_extrinsic(self):
@@ -61,7 +69,12 @@ class SameSettingImageData:
 
     @property
     def is_fisheye(self):
-        return False
+        return all(getattr(self, a) is not None for a in self._fisheye_keys)
+
+    @property
+    def intrinsic_fisheye(self):
+        """[V, 7] xi, k1, k2, gamma1, gamma2, u0, v0 (image.py:441-454)."""
+        return torch.stack([torch.as_tensor(getattr(self, a)) for a in self._fisheye_keys]).T
 
     @property
     def intrinsic_pinhole(self):
@@ -107,7 +120,8 @@ class SameSettingImageData:
             downscale=copy.deepcopy(self.downscale),
             crop_size=copy.deepcopy(self.crop_size), crop_offsets=self.crop_offsets[idx],
             x=sel(self.x), mask=self.mask.clone() if self.mask is not None else None,
-            visibility=copy.deepcopy(self.visibility))
+            visibility=copy.deepcopy(self.visibility), opk=sel(self.opk),
+            **{a: sel(getattr(self, a)) for a in self._fisheye_keys})
 
     def __iter__(self):
         for i in range(len(self)):

@@ -367,6 +367,8 @@ class MapImages(ImageTransform):
             ('scattering', 'scattering'), ('normals', 'norm'))}
         attrs = {k: (a.to(device).float() if a is not None else None) for k, a in attrs.items()}
         K = images.intrinsic_pinhole.float() if images.is_pinhole else None
+        fish = images.intrinsic_fisheye.float() if getattr(images, 'is_fisheye', False) else None
+        opk = images.opk.float() if getattr(images, 'has_opk', False) else None
         r = float(visi_model.r_max)
 
         image_ids, point_ids, features, pixels = [], [], [], []
@@ -381,7 +383,9 @@ class MapImages(ImageTransform):
                 extra['depth_map'] = images.depth_maps[v]
             out_vm = visi_model(
                 pos32[local], images.pos[v].float(),
+                img_opk=opk[v] if opk is not None else None,
                 img_intrinsic_pinhole=K[v] if K is not None else None,
+                img_intrinsic_fisheye=fish[v] if fish is not None else None,
                 img_extrinsic=images.extrinsic[v].float() if images.has_extrinsic else None,
                 img_mask=images.mask if images.mask is not None else None,
                 **{k: (a[local] if a is not None else None) for k, a in attrs.items()},

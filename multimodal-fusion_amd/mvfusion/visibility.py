@@ -1,6 +1,7 @@
-"""Host-side mirror of ``torch_points3d/core/multimodal/visibility.py`` for the
-pinhole cameras: same function / class names, arguments and return values, with
-the computation done by the HIP kernels of libmvfusion.so.
+"""Host-side mirror of ``torch_points3d/core/multimodal/visibility.py``: same
+function / class names, arguments and return values, with the computation done
+by the HIP kernels of libmvfusion.so.  Cameras: 'kitti360_perspective',
+'scannet', 'kitti360_fisheye', 's3dis_equirectangular'.
 
 Reference lines (relative to DeepViewAgg-Wildscenes/torch_points3d/):
 ``camera_projection`` core/multimodal/visibility.py:592-623 (CPU body :478-538),
@@ -25,6 +26,23 @@ from . import _lib as L
 
 _PINHOLE = ("kitti360_perspective", "scannet")
 
+# defaults of the reference when an argument is None (visibility.py:13-16)
+_OPK_DEFAULT = (0.0, 0.0, 0.0)
+_FISHEYE_DEFAULT = (1.0,) * 7
+
+
+def pose_to_rotation_matrix(opk):
+    """pose_to_rotation_matrix_cpu (visibility.py:57-90): float32 rotation from
+    an omega, phi, kappa triplet."""
+    opk = np.asarray(opk, dtype=np.float32).reshape(3)
+    co, so = np.cos(opk[0]), np.sin(opk[0])
+    cp, sp = np.cos(opk[1]), np.sin(opk[1])
+    ck, sk = np.cos(opk[2]), np.sin(opk[2])
+    M_o = np.array([[1.0, 0.0, 0.0], [0.0, co, -so], [0.0, so, co]], dtype=np.float32)
+    M_p = np.array([[cp, 0.0, sp], [0.0, 1.0, 0.0], [-sp, 0.0, cp]], dtype=np.float32)
+    M_k = np.array([[ck, -sk, 0.0], [sk, ck, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    return np.dot(M_o, np.dot(M_p, M_k))
+
 
 def _dev(t, device, dtype=None):
     if t is None:
@@ -34,11 +52,36 @@ def _dev(t, device, dtype=None):
     return t.to(device).contiguous()
 
 
+def _np32(t):
+    return np.asarray(torch.as_tensor(t).detach().cpu().float())
+
+
 def make_view(img_xyz, img_intrinsic_pinhole, img_extrinsic, camera, centre=None,
-              crop_offsets=(0, 0)):
+              crop_offsets=(0, 0), img_opk=None, img_intrinsic_fisheye=None):
     """Pack one view into the C struct (host side)."""
     v = L.MvfView()
     xyz = np.asarray(torch.as_tensor(img_xyz).detach().cpu().float()).reshape(3)
+    if camera in ("kitti360_fisheye", "s3dis_equirectangular"):
+        for i in range(3):
+            v.img_xyz[i] = xyz[i]
+        if camera == "kitti360_fisheye":
+            E = np.eye(4, dtype=np.float32) if img_extrinsic is None else _np32(img_extrinsic)
+            f = np.asarray(_FISHEYE_DEFAULT, np.float32) if img_intrinsic_fisheye is None \
+                else _np32(img_intrinsic_fisheye).reshape(7)
+            M = np.ascontiguousarray(E, dtype=np.float32).reshape(16).copy()
+            M[12:15] = f[0:3]                      # xi, k1, k2 in the unused last row
+            v.fx, v.fy, v.cx, v.cy = float(f[3]), float(f[4]), float(f[5]), float(f[6])
+        else:
+            R = pose_to_rotation_matrix(_OPK_DEFAULT if img_opk is None else _np32(img_opk))
+            M = np.zeros(16, np.float32)
+            M[:9] = R.reshape(9)
+        for i, e in enumerate(M):
+            v.cam_to_world[i] = e
+        c = xyz.astype(np.float64) if centre is None else np.asarray(centre, np.float64).reshape(3)
+        for i in range(3):
+            v.centre[i] = c[i]
+        v.crop_off_x, v.crop_off_y = int(crop_offsets[0]), int(crop_offsets[1])
+        return v
     K = np.eye(4, dtype=np.float32) if img_intrinsic_pinhole is None else \
         np.asarray(torch.as_tensor(img_intrinsic_pinhole).detach().cpu().float())
     E = np.eye(4, dtype=np.float32) if img_extrinsic is None else \
@@ -61,10 +104,7 @@ def make_view(img_xyz, img_intrinsic_pinhole, img_extrinsic, camera, centre=None
 def make_params(img_size=(1024, 512), crop_top=0, crop_bottom=0, r_max=30, r_min=0.5,
                 camera="kitti360_perspective", voxel=0.1, k_swell=1.0, d_swell=1000,
                 exact=False, depth_threshold=0.05, **kwargs):
-    if camera not in _PINHOLE:
-        if camera in ("s3dis_equirectangular", "kitti360_fisheye"):
-            raise NotImplementedError(
-                f"camera '{camera}' is not implemented by the HIP path (pinhole only)")
+    if camera not in L.CAMERAS:
         raise ValueError(f"Unknown camera '{camera}'")
     p = L.MvfVisParams()
     p.W, p.H = int(img_size[0]), int(img_size[1])
@@ -91,7 +131,8 @@ def camera_projection(
     lib = L.load()
     params = make_params(img_size=img_size, crop_top=crop_top, crop_bottom=crop_bottom,
                          r_max=r_max, r_min=r_min, camera=camera)
-    view = make_view(img_xyz, img_intrinsic_pinhole, img_extrinsic, camera)
+    view = make_view(img_xyz, img_intrinsic_pinhole, img_extrinsic, camera,
+                     img_opk=img_opk, img_intrinsic_fisheye=img_intrinsic_fisheye)
     xyz_d = _dev(xyz, device, torch.float32)
     n = xyz_d.shape[0]
     mask_d = _dev(img_mask, device, torch.uint8) if img_mask is not None else None
@@ -128,8 +169,13 @@ def visibility_from_splatting(
     params = make_params(img_size=img_size, crop_top=crop_top, crop_bottom=crop_bottom,
                          camera=camera, voxel=voxel, k_swell=k_swell, d_swell=d_swell,
                          exact=exact)
-    K = torch.eye(4) if img_intrinsic_pinhole is None else img_intrinsic_pinhole
-    fx, fy = float(K[0, 0]), float(K[1, 1])
+    view = make_view(torch.zeros(3), img_intrinsic_pinhole, img_extrinsic, camera,
+                     img_intrinsic_fisheye=img_intrinsic_fisheye)
+    xyz_d = None
+    if camera == 'kitti360_fisheye':
+        # fisheye_splat_cpu projects the lifted points again (visibility.py:900-914)
+        assert xyz is not None and xyz.shape[0] == x_proj.shape[0]
+        xyz_d = _dev(xyz, device, torch.float32)
     x_d = _dev(x_proj, device, torch.float64)
     y_d = _dev(y_proj, device, torch.float64)
     d_d = _dev(dist, device, torch.float32)
@@ -146,8 +192,9 @@ def visibility_from_splatting(
         ws_bytes = lib.mvf_splat_visibility_workspace_bytes(m, W, H, pair_cap)
         ws = L.workspace(ws_bytes, device)
         with torch.cuda.device(device):
-            L.check(lib.mvf_splat_visibility(
-                L.ptr(x_d), L.ptr(y_d), L.ptr(d_d), m, fx, fy, C.byref(params), pair_cap,
+            L.check(lib.mvf_splat_visibility_view(
+                L.ptr(x_d), L.ptr(y_d), L.ptr(d_d), L.ptr(xyz_d), m, C.byref(view),
+                C.byref(params), pair_cap,
                 L.ptr(idx), L.ptr(xo), L.ptr(yo), out_cap, L.ptr(counters),
                 L.ptr(ws), ws.numel(), L.stream_ptr(device)))
         k, pairs, overflow, _ = counters.tolist()
@@ -252,7 +299,8 @@ def _run_visibility(xyz, img_xyz, method, linearity, planarity, scattering, norm
     if x_proj.shape[0] == 0:
         return _empty_out(in_device)
     if method == 'splatting':
-        idx_2, x_pix, y_pix = visibility_from_splatting(x_proj, y_proj, dist, None, **kw)
+        xyz_1 = xyz_d[idx_1] if kw.get('camera') == 'kitti360_fisheye' else None
+        idx_2, x_pix, y_pix = visibility_from_splatting(x_proj, y_proj, dist, xyz_1, **kw)
     elif method == 'depth_map':
         idx_2, x_pix, y_pix = visibility_from_depth_map(x_proj, y_proj, dist, **kw)
     else:

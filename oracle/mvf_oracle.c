@@ -23,7 +23,7 @@
 
 typedef long long i64;
 
-enum { CAM_KITTI360_PERSPECTIVE = 0, CAM_SCANNET = 1 };
+enum { CAM_KITTI360_PERSPECTIVE = 0, CAM_SCANNET = 1, CAM_KITTI360_FISHEYE = 2, CAM_S3DIS_EQUIRECTANGULAR = 3 };
 enum { RED_SUM = 0, RED_MEAN = 1, RED_MIN = 2, RED_MAX = 3 };
 
 /* ------------------------------------------------------------------------ *
@@ -135,30 +135,206 @@ void orc_pinhole_splat(
 }
 
 /* ------------------------------------------------------------------------ *
- * visibility_from_splatting_cpu  (visibility.py:1073-1195), pinhole cameras.
- * Sequential z-buffer over a [W][Hc] depth map, strict '<', points visited in
- * ascending index (:1148-1162); exact=1 re-stamps only the splat centres of
- * the seen points, ascending, later overwrites earlier (:1168-1187); output in
- * np.where order of the [W][Hc] map = sorted by x then y (:1190-1195), y
- * expressed in the non-cropped image.  Outputs need room for
+ * fisheye_projection_cpu  (visibility.py:288-339), 'kitti360_fisheye'.
+ * extrinsic: row-major 4x4 float32 camera-to-world; fisheye: xi, k1, k2,
+ * gamma1, gamma2, u0, v0.  Typing follows numba (not numpy >= 2): a float32
+ * array combined with the float64 literal 1e-4 gives float64, so x, y, z and
+ * everything derived from them are float64; p = R.T @ (xyz - T).T and norm_cpu
+ * stay float32; norm * p[:, 2] is a float32 product divided in float64.
+ * x ** 2 is the exact square (LLVM turns pow(x, 2) into x * x).
+ * PARITY UNPINNED at the bit level: the fixtures come from running the
+ * reference's file without numba, where numpy keeps float32 throughout, so
+ * they pin this function to about 1e-3 pixel only.
+ * ------------------------------------------------------------------------ */
+static void fisheye_point(
+    float px, float py, float pz, const float *M, const float *fisheye,
+    double *xo, double *yo, double *zo)
+{
+    const float e0 = px - M[3], e1 = py - M[7], e2 = pz - M[11];
+    const float p0 = fmaf(M[8], e2, fmaf(M[4], e1, M[0] * e0));
+    const float p1 = fmaf(M[9], e2, fmaf(M[5], e1, M[1] * e0));
+    const float p2 = fmaf(M[10], e2, fmaf(M[6], e1, M[2] * e0));
+    const float s0 = p0 * p0, s1 = p1 * p1, s2 = p2 * p2;
+    const float s01 = s0 + s1;
+    const float ss = s01 + s2;
+    const float norm = sqrtf(ss);
+    const double xi = (double)fisheye[0], k1 = (double)fisheye[1], k2 = (double)fisheye[2];
+    const double g1 = (double)fisheye[3], g2 = (double)fisheye[4];
+    const double u0 = (double)fisheye[5], v0 = (double)fisheye[6];
+    const double den = (double)norm + 1e-4;
+    double x = (double)p0 / den, y = (double)p1 / den;
+    const double z = (double)p2 / den;
+    const double q = z + xi;
+    x = x / q; y = y / q;
+    const double r2 = x * x + y * y;
+    const double r4 = r2 * r2;
+    const double poly = (1.0 + k1 * r2) + k2 * r4;
+    *xo = (g1 * poly) * x + u0;
+    *yo = (g2 * poly) * y + v0;
+    const float np2 = norm * p2;
+    *zo = (double)np2 / fabs((double)p2 + 1e-4);
+}
+
+void orc_fisheye_projection(
+    i64 n, const float *xyz, const float *extrinsic, const float *fisheye,
+    double *x, double *y, double *z)
+{
+    for (i64 i = 0; i < n; ++i)
+        fisheye_point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], extrinsic, fisheye,
+                      x + i, y + i, z + i);
+}
+
+/* a % b of numpy for float64, b > 0 */
+static inline double py_mod(double a, double b)
+{
+    double r = fmod(a, b);
+    if (r != 0.0 && r < 0.0) r += b;
+    return r;
+}
+
+/* ------------------------------------------------------------------------ *
+ * equirectangular_projection_cpu  (visibility.py:150-182).  xyz_to_img =
+ * xyz - img_xyz, radius = its norm (float32); rotation: row-major 3x3 float32
+ * from pose_to_rotation_matrix_cpu (:57-90, computed by the caller).
+ * v = xyz_to_img.dot(rotation.T) is the sgemm fmaf chain in k order 0,1,2
+ * (measured against numpy on the build host: 0 of 3e6 values differ).
+ * arctan2 / arccos of float32 operands are taken correctly rounded (float64
+ * evaluation, then rounding): the reference's libm atan2f / acosf may differ
+ * from that in the last bit.  Typing follows numba: t / np.pi is float64,
+ * (height - 1) * p is a float32 product, then / np.pi in float64.
+ * PARITY UNPINNED at the bit level (see orc_fisheye_projection).
+ * ------------------------------------------------------------------------ */
+void orc_equirectangular_projection(
+    i64 n, const float *xyz_to_img, const float *radius, const float *rotation,
+    int W, int H, double *x, double *y)
+{
+    const float *R = rotation;
+    for (i64 i = 0; i < n; ++i) {
+        const float d0 = xyz_to_img[3 * i], d1 = xyz_to_img[3 * i + 1], d2 = xyz_to_img[3 * i + 2];
+        const float v0 = fmaf(R[2], d2, fmaf(R[1], d1, R[0] * d0));
+        const float v1 = fmaf(R[5], d2, fmaf(R[4], d1, R[3] * d0));
+        const float v2 = fmaf(R[8], d2, fmaf(R[7], d1, R[6] * d0));
+        const float t = (float)atan2((double)v1, (double)v0);
+        const float c = v2 / radius[i];
+        const float p = (float)acos((double)c);
+        const double w1 = 1.0 - (double)t / M_PI;
+        const double w2 = (double)(W - 1) * w1;
+        double wp = py_mod(w2 / 2.0, (double)W);
+        const float hp32 = (float)(H - 1) * p;
+        double hp = py_mod((double)hp32 / M_PI, (double)H);
+        if (isnan(wp)) wp = 0.0;
+        if (isnan(hp)) hp = 0.0;
+        x[i] = wp; y[i] = hp;
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * field_of_view_cpu  (visibility.py:395-435) on float64 coordinates.  z may be
+ * NULL (then taken as 1, :525).  Returns the count; out_idx ascending.
+ * ------------------------------------------------------------------------ */
+i64 orc_field_of_view(
+    i64 n, const double *x, const double *y, const double *z, const unsigned char *mask,
+    int W, int H, int crop_top, int crop_bottom, i64 *out_idx)
+{
+    i64 m = 0;
+    for (i64 i = 0; i < n; ++i) {
+        if (!(0.0 <= x[i])) continue;
+        if (!((double)crop_top <= y[i])) continue;
+        if (!(x[i] < (double)W)) continue;
+        if (!(y[i] < (double)(H - crop_bottom))) continue;
+        if (z && !(0.0 < z[i])) continue;
+        if (mask) {
+            const uint32_t xi = (uint32_t)floor(x[i]), yi = (uint32_t)floor(y[i]);
+            if (!mask[(size_t)xi * H + yi]) continue;
+        }
+        out_idx[m++] = i;
+    }
+    return m;
+}
+
+/* boxes from float64 widths, common tail of the three *_splat_cpu functions
+ * (visibility.py:667-702, 807-825, 916-951) */
+static void splat_box(
+    double x, double y, double wx, double wy, int W, int H, int crop_top, int crop_bottom,
+    int32_t *out)
+{
+    const int32_t x_min = 0, x_max = W, y_min = crop_top, y_max = H - crop_bottom;
+    out[0] = clampi(round_f64_to_i32(x - wx / 2), x_min, x_max - 1);
+    out[1] = clampi(round_f64_to_i32(x + wx / 2 + 1), x_min + 1, x_max);
+    out[2] = clampi(round_f64_to_i32(y - wy / 2), y_min, y_max - 1);
+    out[3] = clampi(round_f64_to_i32(y + wy / 2 + 1), y_min + 1, y_max);
+}
+
+/* ------------------------------------------------------------------------ *
+ * equirectangular_splat_cpu  (visibility.py:630-704), all float64.
+ * ------------------------------------------------------------------------ */
+void orc_equirectangular_splat(
+    i64 m, const double *x_proj, const double *y_proj, const float *dist,
+    int W, int H, int crop_top, int crop_bottom,
+    double voxel, double k_swell, double d_swell, int32_t *splat)
+{
+    const double ln_d = log(d_swell);
+    const double b = M_PI / (double)H;
+    for (i64 i = 0; i < m; ++i) {
+        const double d = (double)dist[i];
+        const double aw = (1.0 + k_swell * exp(-d / ln_d)) * voxel / d;
+        const double res_y = aw * (double)H / M_PI;
+        const double a = aw * (double)W / (2.0 * M_PI);
+        const double res_x = a / (sin(b * y_proj[i]) + 0.001);
+        splat_box(x_proj[i], y_proj[i], res_x, res_y, W, H, crop_top, crop_bottom, splat + 4 * i);
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * fisheye_splat_cpu  (visibility.py:876-953).  xyz: WORLD coordinates of the
+ * m splats; the swell uses norm_cpu(xyz), i.e. the distance to the world
+ * origin, exactly as written at :900.  z_offset is a float32 array, so
+ * swell * voxel / 2 is rounded to float32 before the float32 addition to z.
+ * ------------------------------------------------------------------------ */
+void orc_fisheye_splat(
+    i64 m, const double *x_proj, const double *y_proj, const float *xyz,
+    const float *extrinsic, const float *fisheye, int W, int H, int crop_top, int crop_bottom,
+    double voxel, double k_swell, double d_swell, int32_t *splat)
+{
+    const double ln_d = log(d_swell);
+    for (i64 i = 0; i < m; ++i) {
+        const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
+        const float s0 = px * px, s1 = py * py, s2 = pz * pz;
+        const float s01 = s0 + s1;
+        const float ss = s01 + s2;
+        const float nw = sqrtf(ss);
+        const double swell = 1.0 + k_swell * exp(-(double)nw / ln_d);
+        const float lift = (float)(swell * voxel / 2);
+        const float pz2 = pz + lift;
+        double x, y, z;
+        fisheye_point(px, py, pz2, extrinsic, fisheye, &x, &y, &z);
+        const double dx = x_proj[i] - x, dy = y_proj[i] - y;
+        const double w = 2.0 * sqrt(dx * dx + dy * dy);
+        splat_box(x_proj[i], y_proj[i], w, w, W, H, crop_top, crop_bottom, splat + 4 * i);
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * visibility_from_splatting_cpu  (visibility.py:1073-1195) from the boxes of
+ * any of the *_splat_cpu functions (splat: [m][4], not yet shifted by
+ * crop_top).  Sequential z-buffer over a [W][Hc] depth map, strict '<', points
+ * visited in ascending index (:1148-1162); exact=1 re-stamps only the splat
+ * centres of the seen points, ascending, later overwrites earlier
+ * (:1168-1187); output in np.where order of the [W][Hc] map = sorted by x then
+ * y (:1190-1195), y expressed in the non-cropped image.  Outputs need room for
  * min(m, W*Hc) (exact) or W*Hc (non exact) entries.  Returns the count, or -1
  * on allocation failure.
  * ------------------------------------------------------------------------ */
-i64 orc_visibility_from_splatting(
+i64 orc_zbuffer_from_splat(
     i64 m, const double *x_proj, const double *y_proj, const float *dist,
-    float fx, float fy, int W, int H, int crop_top, int crop_bottom,
-    double voxel, double k_swell, double d_swell, int exact,
+    const int32_t *splat, int W, int H, int crop_top, int crop_bottom, int exact,
     i64 *out_idx, i64 *out_x, i64 *out_y)
 {
     const int Hc = H - crop_bottom - crop_top;
     const size_t npix = (size_t)W * Hc;
-    int32_t *splat = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)(m > 0 ? m : 1));
     float *depth = (float *)malloc(sizeof(float) * npix);
     i64 *idmap = (i64 *)malloc(sizeof(i64) * npix);
-    if (!splat || !depth || !idmap) { free(splat); free(depth); free(idmap); return -1; }
-
-    orc_pinhole_splat(m, x_proj, y_proj, dist, fx, fy, W, H, crop_top,
-                      crop_bottom, voxel, k_swell, d_swell, splat);
+    if (!depth || !idmap) { free(depth); free(idmap); return -1; }
 
     float dmax = dist[0];
     for (i64 i = 1; i < m; ++i) if (dist[i] > dmax) dmax = dist[i];
@@ -180,7 +356,7 @@ i64 orc_visibility_from_splatting(
 
     if (exact) {
         unsigned char *seen = (unsigned char *)calloc((size_t)(m > 0 ? m : 1), 1);
-        if (!seen) { free(splat); free(depth); free(idmap); return -1; }
+        if (!seen) { free(depth); free(idmap); return -1; }
         for (size_t p = 0; p < npix; ++p) if (idmap[p] >= 0) seen[idmap[p]] = 1;
         for (size_t p = 0; p < npix; ++p) idmap[p] = -1;
         for (i64 i = 0; i < m; ++i) {
@@ -198,7 +374,24 @@ i64 orc_visibility_from_splatting(
             const i64 id = idmap[(size_t)x * Hc + y];
             if (id >= 0) { out_idx[k] = id; out_x[k] = x; out_y[k] = y + crop_top; ++k; }
         }
-    free(splat); free(depth); free(idmap);
+    free(depth); free(idmap);
+    return k;
+}
+
+/* visibility_from_splatting_cpu for the pinhole cameras (:1121-1125) */
+i64 orc_visibility_from_splatting(
+    i64 m, const double *x_proj, const double *y_proj, const float *dist,
+    float fx, float fy, int W, int H, int crop_top, int crop_bottom,
+    double voxel, double k_swell, double d_swell, int exact,
+    i64 *out_idx, i64 *out_x, i64 *out_y)
+{
+    int32_t *splat = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)(m > 0 ? m : 1));
+    if (!splat) return -1;
+    orc_pinhole_splat(m, x_proj, y_proj, dist, fx, fy, W, H, crop_top,
+                      crop_bottom, voxel, k_swell, d_swell, splat);
+    const i64 k = orc_zbuffer_from_splat(m, x_proj, y_proj, dist, splat, W, H, crop_top,
+                                         crop_bottom, exact, out_idx, out_x, out_y);
+    free(splat);
     return k;
 }
 

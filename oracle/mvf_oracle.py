@@ -23,7 +23,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libmvf_oracle.so")
 
-CAMERAS = {"kitti360_perspective": 0, "scannet": 1}
+CAMERAS = {"kitti360_perspective": 0, "scannet": 1, "kitti360_fisheye": 2,
+           "s3dis_equirectangular": 3}
+PINHOLE = ("kitti360_perspective", "scannet")
 REDUCE = {"sum": 0, "add": 0, "mean": 1, "min": 2, "max": 3}
 
 
@@ -44,6 +46,8 @@ def _lib():
     _LIB.orc_visibility_from_splatting.restype = C.c_longlong
     _LIB.orc_visibility_from_depth_map.restype = C.c_longlong
     _LIB.orc_postprocess_features.restype = C.c_int
+    _LIB.orc_field_of_view.restype = C.c_longlong
+    _LIB.orc_zbuffer_from_splat.restype = C.c_longlong
     return _LIB
 
 
@@ -59,11 +63,92 @@ def _c(a, dt):
 # visibility.py                                                               #
 # --------------------------------------------------------------------------- #
 
+def pose_to_rotation_matrix(opk):
+    """pose_to_rotation_matrix_cpu, visibility.py:57-90 (float32 throughout)."""
+    opk = np.asarray(opk, dtype=np.float32).reshape(3)
+    co, so = np.cos(opk[0]), np.sin(opk[0])
+    cp, sp = np.cos(opk[1]), np.sin(opk[1])
+    ck, sk = np.cos(opk[2]), np.sin(opk[2])
+    M_o = np.array([[1.0, 0.0, 0.0], [0.0, co, -so], [0.0, so, co]], dtype=np.float32)
+    M_p = np.array([[cp, 0.0, sp], [0.0, 1.0, 0.0], [-sp, 0.0, cp]], dtype=np.float32)
+    M_k = np.array([[ck, -sk, 0.0], [sk, ck, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    return np.dot(M_o, np.dot(M_p, M_k))
+
+
+def _norm(v):
+    """norm_cpu, visibility.py:129-137: float32, squares added in column order."""
+    v = _c(v, np.float32)
+    s = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]) + v[:, 2] * v[:, 2]
+    return np.sqrt(s)
+
+
+def fisheye_projection(xyz, img_extrinsic, img_intrinsic_fisheye):
+    """fisheye_projection_cpu, visibility.py:288-339 (numba typing)."""
+    xyz = _c(xyz, np.float32)
+    n = xyz.shape[0]
+    x, y, z = (np.empty(n, np.float64) for _ in range(3))
+    _lib().orc_fisheye_projection(
+        C.c_longlong(n), _p(xyz), _p(_c(img_extrinsic, np.float32)),
+        _p(_c(img_intrinsic_fisheye, np.float32)), _p(x), _p(y), _p(z))
+    return x, y, z
+
+
+def equirectangular_projection(xyz_to_img, radius, img_opk, img_size):
+    """equirectangular_projection_cpu, visibility.py:150-182 (numba typing)."""
+    d = _c(xyz_to_img, np.float32)
+    n = d.shape[0]
+    R = np.ascontiguousarray(pose_to_rotation_matrix(img_opk), dtype=np.float32)
+    x, y = np.empty(n, np.float64), np.empty(n, np.float64)
+    _lib().orc_equirectangular_projection(
+        C.c_longlong(n), _p(d), _p(_c(radius, np.float32)), _p(R),
+        int(img_size[0]), int(img_size[1]), _p(x), _p(y))
+    return x, y
+
+
+def _camera_projection_wide(
+        xyz, img_xyz, img_opk, img_intrinsic_fisheye, img_extrinsic, img_mask,
+        img_size, crop_top, crop_bottom, r_max, r_min, camera):
+    """camera_projection_cpu, visibility.py:478-538, fisheye / equirectangular
+    branches (:519-527)."""
+    xyz = _c(xyz, np.float32)
+    img_xyz = _c(img_xyz, np.float32).reshape(3)
+    indices = np.arange(xyz.shape[0])
+    dist = _norm(xyz - img_xyz)
+    in_range = np.where(np.logical_and(r_min < dist.astype(np.float64),
+                                       dist.astype(np.float64) < r_max))[0]
+    xyz, dist, indices = xyz[in_range], dist[in_range], indices[in_range]
+    if camera == "kitti360_fisheye":
+        E = np.eye(4, dtype=np.float32) if img_extrinsic is None else img_extrinsic
+        f = np.ones(7, np.float32) if img_intrinsic_fisheye is None else img_intrinsic_fisheye
+        x, y, z = fisheye_projection(xyz, E, f)
+    else:
+        opk = np.zeros(3, np.float32) if img_opk is None else img_opk
+        x, y = equirectangular_projection(xyz - img_xyz, dist, opk, img_size)
+        z = None
+    W, H = int(img_size[0]), int(img_size[1])
+    mask = None
+    if img_mask is not None:
+        assert tuple(img_mask.shape) == (W, H)
+        mask = _c(img_mask, np.uint8)
+    keep = np.empty(x.shape[0], np.int64)
+    m = _lib().orc_field_of_view(
+        C.c_longlong(x.shape[0]), _p(x), _p(y), _p(z), _p(mask), W, H,
+        int(crop_top), int(crop_bottom), _p(keep))
+    keep = keep[:m]
+    return indices[keep].astype(np.int64), dist[keep], x[keep], y[keep]
+
+
 def camera_projection(
-        xyz, img_xyz, img_intrinsic_pinhole=None, img_extrinsic=None,
-        img_mask=None, img_size=(1024, 512), crop_top=0, crop_bottom=0,
+        xyz, img_xyz, img_opk=None, img_intrinsic_pinhole=None, img_intrinsic_fisheye=None,
+        img_extrinsic=None, img_mask=None, img_size=(1024, 512), crop_top=0, crop_bottom=0,
         r_max=30, r_min=0.5, camera="kitti360_perspective", **kwargs):
-    """camera_projection_cpu, visibility.py:478-538 (pinhole cameras)."""
+    """camera_projection_cpu, visibility.py:478-538."""
+    if camera not in PINHOLE:
+        if camera not in CAMERAS:
+            raise ValueError(camera)
+        return _camera_projection_wide(
+            xyz, img_xyz, img_opk, img_intrinsic_fisheye, img_extrinsic, img_mask,
+            img_size, crop_top, crop_bottom, r_max, r_min, camera)
     xyz = _c(xyz, np.float32)
     n = xyz.shape[0]
     K = np.eye(4, dtype=np.float32) if img_intrinsic_pinhole is None \
@@ -105,15 +190,70 @@ def pinhole_splat(
     return splat
 
 
+def equirectangular_splat(
+        x_proj, y_proj, dist, img_size=(1024, 512), crop_top=0, crop_bottom=0,
+        voxel=0.02, k_swell=1.0, d_swell=1000):
+    """equirectangular_splat_cpu, visibility.py:630-704."""
+    m = x_proj.shape[0]
+    splat = np.empty((m, 4), np.int32)
+    _lib().orc_equirectangular_splat(
+        C.c_longlong(m), _p(_c(x_proj, np.float64)), _p(_c(y_proj, np.float64)),
+        _p(_c(dist, np.float32)), int(img_size[0]), int(img_size[1]), int(crop_top),
+        int(crop_bottom), C.c_double(voxel), C.c_double(k_swell), C.c_double(d_swell),
+        _p(splat))
+    return splat
+
+
+def fisheye_splat(
+        x_proj, y_proj, xyz, img_extrinsic, img_intrinsic_fisheye, img_size=(1024, 512),
+        crop_top=0, crop_bottom=0, voxel=0.02, k_swell=1.0, d_swell=1000):
+    """fisheye_splat_cpu, visibility.py:876-953."""
+    m = x_proj.shape[0]
+    splat = np.empty((m, 4), np.int32)
+    _lib().orc_fisheye_splat(
+        C.c_longlong(m), _p(_c(x_proj, np.float64)), _p(_c(y_proj, np.float64)),
+        _p(_c(xyz, np.float32)), _p(_c(img_extrinsic, np.float32)),
+        _p(_c(img_intrinsic_fisheye, np.float32)), int(img_size[0]), int(img_size[1]),
+        int(crop_top), int(crop_bottom), C.c_double(voxel), C.c_double(k_swell),
+        C.c_double(d_swell), _p(splat))
+    return splat
+
+
+def _zbuffer(x_proj, y_proj, dist, splat, img_size, crop_top, crop_bottom, exact):
+    """z-buffer part of visibility_from_splatting_cpu, visibility.py:1134-1195."""
+    m = x_proj.shape[0]
+    W, H = int(img_size[0]), int(img_size[1])
+    cap = min(m, W * (H - crop_top - crop_bottom)) if exact \
+        else W * (H - crop_top - crop_bottom)
+    idx, xo, yo = (np.empty(cap, np.int64) for _ in range(3))
+    k = _lib().orc_zbuffer_from_splat(
+        C.c_longlong(m), _p(_c(x_proj, np.float64)), _p(_c(y_proj, np.float64)),
+        _p(_c(dist, np.float32)), _p(np.ascontiguousarray(splat, np.int32)), W, H,
+        int(crop_top), int(crop_bottom), int(bool(exact)), _p(idx), _p(xo), _p(yo))
+    if k < 0:
+        raise MemoryError
+    return idx[:k].copy(), xo[:k].copy(), yo[:k].copy()
+
+
 def visibility_from_splatting(
         x_proj, y_proj, dist, xyz=None, img_extrinsic=None,
-        img_intrinsic_pinhole=None, img_size=(1024, 512), crop_top=0,
-        crop_bottom=0, voxel=0.1, k_swell=1.0, d_swell=1000, exact=False,
+        img_intrinsic_pinhole=None, img_intrinsic_fisheye=None, img_size=(1024, 512),
+        crop_top=0, crop_bottom=0, voxel=0.1, k_swell=1.0, d_swell=1000, exact=False,
         camera="kitti360_perspective", **kwargs):
-    """visibility_from_splatting_cpu, visibility.py:1073-1195 (pinhole)."""
+    """visibility_from_splatting_cpu, visibility.py:1073-1195."""
     assert camera in CAMERAS
     m = x_proj.shape[0]
     assert m > 0 and y_proj.shape[0] == m and dist.shape[0] == m
+    if camera == "s3dis_equirectangular":
+        splat = equirectangular_splat(x_proj, y_proj, dist, img_size, crop_top, crop_bottom,
+                                      voxel, k_swell, d_swell)
+        return _zbuffer(x_proj, y_proj, dist, splat, img_size, crop_top, crop_bottom, exact)
+    if camera == "kitti360_fisheye":
+        E = np.eye(4, dtype=np.float32) if img_extrinsic is None else img_extrinsic
+        f = np.ones(7, np.float32) if img_intrinsic_fisheye is None else img_intrinsic_fisheye
+        splat = fisheye_splat(x_proj, y_proj, xyz, E, f, img_size, crop_top, crop_bottom,
+                              voxel, k_swell, d_swell)
+        return _zbuffer(x_proj, y_proj, dist, splat, img_size, crop_top, crop_bottom, exact)
     K = np.eye(4, dtype=np.float32) if img_intrinsic_pinhole is None \
         else _c(img_intrinsic_pinhole, np.float32)
     W, H = int(img_size[0]), int(img_size[1])
@@ -556,7 +696,9 @@ def map_images(
         timings=None, **vis_kw):
     """MapImages._process, core/data_transform/multimodal/image.py:192-428.
 
-    ``cams``: dict with pos [V,3] float64, extrinsic [V,4,4], fx, fy, mx, my [V].
+    ``cams``: dict with pos [V,3] float64 and, per camera model, extrinsic
+    [V,4,4] + fx, fy, mx, my [V] (pinhole), extrinsic + fisheye [V,7]
+    (xi, k1, k2, gamma1, gamma2, u0, v0) or opk [V,3] (equirectangular).
     ``order``: permutation of the points in the traversal order of the
     reference's KDTree(leaf_size=50) -- ``tree.idx_array`` -- which fixes the
     local point order of every per-image sample (transforms.py:332,386); None
@@ -592,17 +734,25 @@ def map_images(
         local = order[d2 <= float(r_max) * float(r_max)]
         g = lambda a: None if a is None else np.asarray(a)[local]
         t1 = time.perf_counter()
-        K = np.eye(4, dtype=np.float32)
-        K[0, 0], K[1, 1] = cams["fx"][v], cams["fy"][v]
-        K[0, 2], K[1, 2] = cams["mx"][v], cams["my"][v]
+        K = None
+        if cams.get("fx") is not None:
+            K = np.eye(4, dtype=np.float32)
+            K[0, 0], K[1, 1] = cams["fx"][v], cams["fy"][v]
+            K[0, 2], K[1, 2] = cams["mx"][v], cams["my"][v]
         kw = dict(vis_kw)
+        # image.py:276-279: opk / fisheye intrinsics / extrinsic when the images hold them
+        if cams.get("opk") is not None:
+            kw["img_opk"] = np.asarray(cams["opk"][v], np.float32)
+        if cams.get("fisheye") is not None:
+            kw["img_intrinsic_fisheye"] = np.asarray(cams["fisheye"][v], np.float32)
         if depth_maps is not None:
             kw["depth_map"] = depth_maps[v]
         out = visibility_model(
             pos32[local], cams["pos"][v].astype(np.float32), method=method,
             linearity=g(linearity), planarity=g(planarity),
             scattering=g(scattering), normals=g(normals),
-            img_intrinsic_pinhole=K, img_extrinsic=cams["extrinsic"][v],
+            img_intrinsic_pinhole=K,
+            img_extrinsic=None if cams.get("extrinsic") is None else cams["extrinsic"][v],
             img_mask=img_mask, img_size=proj_size, **kw)
         t2 = time.perf_counter()
         T["sample"] += t1 - t0

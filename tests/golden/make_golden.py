@@ -117,6 +117,65 @@ def gen_visibility():
              voxel=0.05, k_swell=1.5, d_swell=1e6, splat=splat, **out)
 
 
+# ----------------------------------------- fisheye / equirectangular cameras
+def gen_wide_cameras():
+    """camera_projection + the camera's *_splat_cpu + visibility_from_splatting
+    for 'kitti360_fisheye' and 's3dis_equirectangular'.  NB: the reference's
+    file runs here without numba, i.e. with numpy >= 2 typing (float32 arrays
+    stay float32 next to Python float literals) where numba computes in
+    float64: these fixtures pin the formulas to about 1e-3 pixel, not to the
+    bit."""
+    sc = S.make_scene("c1", seed=7, n_points=15000)
+    xyz = sc["xyz"]
+    kw = dict(voxel=0.05, k_swell=1.5, d_swell=1e6)
+    cams = {
+        "fisheye": dict(
+            camera="kitti360_fisheye", img_size=(700, 700), v=2, crop_top=0, crop_bottom=0,
+            fisheye=np.array([2.2134, 0.016, 0.4325, 668.2, 667.9, 358.4, 352.9], np.float32)),
+        "equirect": dict(
+            camera="s3dis_equirectangular", img_size=(1024, 512), v=5, crop_top=30,
+            crop_bottom=20, opk=np.array([0.05, -0.1, 1.2], np.float32)),
+    }
+    for name, c in cams.items():
+        v, (W, H) = c["v"], c["img_size"]
+        E = sc["extrinsic"][v]
+        img_xyz = sc["pos"][v].astype(np.float32)
+        f = c.get("fisheye")
+        opk = c.get("opk")
+        common = dict(img_size=(W, H), crop_top=c["crop_top"], crop_bottom=c["crop_bottom"],
+                      camera=c["camera"])
+        idx1, dist, xp, yp = vis.camera_projection(
+            T(xyz), T(img_xyz), img_opk=None if opk is None else T(opk),
+            img_intrinsic_fisheye=None if f is None else T(f), img_extrinsic=T(E),
+            r_max=20, r_min=0.5, **common)
+        xyz1 = T(xyz)[idx1]
+        if name == "fisheye":
+            splat = vis.fisheye_splat_cpu(
+                xp.numpy(), yp.numpy(), xyz1.numpy(), E, f, img_size=(W, H),
+                crop_top=c["crop_top"], crop_bottom=c["crop_bottom"],
+                camera=c["camera"], **kw)
+        else:
+            splat = vis.equirectangular_splat_cpu(
+                xp.numpy(), yp.numpy(), dist.numpy(), img_size=(W, H),
+                crop_top=c["crop_top"], crop_bottom=c["crop_bottom"], **kw)
+        out = {}
+        for exact in (False, True):
+            i2, xpix, ypix = vis.visibility_from_splatting(
+                xp, yp, dist, xyz1, img_extrinsic=T(E),
+                img_intrinsic_fisheye=None if f is None else T(f), exact=exact,
+                **common, **kw)
+            tag = "exact" if exact else "splat"
+            out[f"{tag}_idx"] = i2.numpy()
+            out[f"{tag}_x"] = xpix.numpy()
+            out[f"{tag}_y"] = ypix.numpy()
+        save(f"wide_{name}", xyz=xyz, img_xyz=img_xyz, extrinsic=E,
+             fisheye=np.zeros(0) if f is None else f, opk=np.zeros(0) if opk is None else opk,
+             img_size=np.array([W, H]), crop_top=c["crop_top"], crop_bottom=c["crop_bottom"],
+             r_max=20.0, r_min=0.5, camera=c["camera"], voxel=0.05, k_swell=1.5, d_swell=1e6,
+             indices=idx1.numpy(), dist=dist.numpy(), x_proj=xp.numpy(), y_proj=yp.numpy(),
+             splat=splat, **out)
+
+
 # --------------------------------------------------- visibility model + feats
 def gen_model():
     sc = S.make_scene("c1", seed=2, n_points=15000)
@@ -491,7 +550,7 @@ def gen_attention_variants():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or [
-        "projection", "visibility", "model", "depth_map", "map_images", "lexops",
+        "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
         "from_dense", "select_points", "pooling", "attention_pools", "attention_variants"]
     for w in which:
         globals()["gen_" + w]()

@@ -58,8 +58,6 @@ def test_camera_projection_empty_and_cpu_input(golden):
         img_extrinsic=T(g["extrinsic"]), img_size=tuple(g["img_size"]),
         r_max=20, r_min=0, camera="kitti360_perspective")
     assert not idx.is_cuda and np.array_equal(idx.numpy(), g["indices"])
-    with pytest.raises(NotImplementedError):
-        camera_projection(dev(g["xyz"]), T(g["img_xyz"]), camera="s3dis_equirectangular")
     with pytest.raises(ValueError):
         camera_projection(dev(g["xyz"]), T(g["img_xyz"]), camera="nope")
 

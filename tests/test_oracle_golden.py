@@ -45,6 +45,50 @@ def test_splat_and_zbuffer(golden, name):
         assert np.array_equal(y, g[tag + "_y"]), tag
 
 
+def wide_camera_kwargs(g):
+    """Arguments of a wide_* fixture for camera_projection / visibility_from_splatting."""
+    W, H = (int(v) for v in g["img_size"])
+    proj = dict(img_opk=g["opk"] if g["opk"].size else None,
+                img_intrinsic_fisheye=g["fisheye"] if g["fisheye"].size else None,
+                img_extrinsic=g["extrinsic"], img_size=(W, H), crop_top=int(g["crop_top"]),
+                crop_bottom=int(g["crop_bottom"]), camera=str(g["camera"]))
+    splat = dict(voxel=float(g["voxel"]), k_swell=float(g["k_swell"]),
+                 d_swell=float(g["d_swell"]))
+    return proj, splat
+
+
+@pytest.mark.parametrize("name", ["fisheye", "equirect"])
+def test_wide_cameras(golden, name):
+    """'kitti360_fisheye' / 's3dis_equirectangular'.  The fixture was produced
+    by the reference's file under numpy typing (float32 kept next to Python
+    float literals), the oracle follows numba's typing (float64 there): the
+    coordinates agree to a fraction of 1e-3 pixel, the integer results are
+    compared exactly and do agree on these inputs.  Bit-level parity of these
+    two cameras is otherwise unpinned."""
+    g = golden("wide_" + name)
+    proj, splat_kw = wide_camera_kwargs(g)
+    idx, dist, x, y = orc.camera_projection(
+        g["xyz"], g["img_xyz"], r_max=float(g["r_max"]), r_min=float(g["r_min"]), **proj)
+    assert np.array_equal(idx, g["indices"])
+    assert np.array_equal(dist.view(np.uint32), g["dist"].view(np.uint32))
+    assert np.abs(x - g["x_proj"]).max() < 1e-3 and np.abs(y - g["y_proj"]).max() < 1e-3
+    size = dict(img_size=proj["img_size"], crop_top=proj["crop_top"],
+                crop_bottom=proj["crop_bottom"])
+    if name == "fisheye":
+        splat = orc.fisheye_splat(x, y, g["xyz"][idx], g["extrinsic"], g["fisheye"],
+                                  **size, **splat_kw)
+    else:
+        splat = orc.equirectangular_splat(x, y, dist, **size, **splat_kw)
+    assert np.abs(splat - g["splat"]).max() <= 1
+    assert (splat == g["splat"]).all(axis=1).mean() > 0.999
+    for tag, exact in (("splat", False), ("exact", True)):
+        i2, xp, yp = orc.visibility_from_splatting(
+            x, y, dist, g["xyz"][idx], exact=exact, **proj, **splat_kw)
+        assert np.array_equal(i2, g[tag + "_idx"]), tag
+        assert np.array_equal(xp, g[tag + "_x"]), tag
+        assert np.array_equal(yp, g[tag + "_y"]), tag
+
+
 @pytest.mark.parametrize("name", ["full", "bare"])
 def test_visibility_model(golden, name):
     from mvfusion import synthetic as S
