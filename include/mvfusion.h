@@ -252,6 +252,22 @@ int mvf_gather_pool(
     const int64_t *view_ptr, const int16_t *pixels, int64_t rows, int32_t reduce, float *out,
     void *stream);
 
+/* X[mappings.feature_map_indexing] (core/multimodal/image.py:1295,1881-1895):
+ * out[p][c] = x[batch[p]][c][pixels[p][1]][pixels[p][0]] for x of shape
+ * [B][C][H][W]; batch [rows], pixels [rows][2] = (column, row).  The caller
+ * guarantees batch < B and pixels inside the map. */
+int mvf_gather_features(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *batch,
+    const int16_t *pixels, int64_t rows, float *out, void *stream);
+
+/* sparse_interpolation (core/multimodal/image.py:105-170): bilinear sampling
+ * of x [B][C][H][W] at coords [rows][2] = (row, column) in [0, 1] on the map
+ * padded by one pixel.  padding_mode: 0 'border', 1 'zeros', 2 'reflection'.
+ * out: [rows][C]. */
+int mvf_sparse_interpolation(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const float *coords,
+    const int64_t *batch, int64_t rows, int32_t padding_mode, float *out, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* attentive pools: QKVBimodalCSRPool / GroupBimodalCSRPool / DeepSetFeat       */
 /* ------------------------------------------------------------------------- */

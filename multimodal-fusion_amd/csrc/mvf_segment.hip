@@ -269,6 +269,101 @@ __global__ __launch_bounds__(256) void gather_pool_kernel(
     }
 }
 
+// Feature-map gather: out[p][c] = x[batch[p]][c][py[p]][px[p]] for x of shape
+// [B][C][H][W] -- X[mappings.feature_map_indexing] of the reference
+// (core/multimodal/image.py:1295, 1881-1895).  Lane = mapped pixel, four
+// channels in flight per lane; the [64][64-channel] tile goes through LDS so
+// that the output rows are written contiguously.
+__global__ __launch_bounds__(256) void gather_features_kernel(
+    const float *__restrict__ x, int C, int H, int W, const i64 *__restrict__ batch,
+    const int16_t *__restrict__ pixels, i64 rows, float *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const i64 r = (i64)blockIdx.x * 64 + row;
+    const size_t hw = (size_t)H * W;
+    const float *px = x;
+    if (r < rows) px = x + (size_t)batch[r] * C * hw + (size_t)pixels[2 * r + 1] * W + pixels[2 * r];
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int c = c0 + cq; c < C && c < c0 + 64; c += 4)
+            tile[row][c - c0] = r < rows ? px[(size_t)c * hw] : 0.f;
+        __syncthreads();
+        const int cw = C - c0 < 64 ? C - c0 : 64;
+        for (int e = threadIdx.x; e < 64 * cw; e += 256) {
+            const int rr = e / cw, cc = e - rr * cw;
+            const i64 ro = (i64)blockIdx.x * 64 + rr;
+            if (ro < rows) out[(size_t)ro * C + c0 + cc] = tile[rr][cc];
+        }
+        __syncthreads();
+    }
+}
+
+// Index of padded row / column i (0 .. n + 1) in the unpadded map, or -1 for a
+// zero: ZeroPad2d(1), ReplicationPad2d(1), ReflectionPad2d(1).
+enum { PAD_BORDER = 0, PAD_ZEROS = 1, PAD_REFLECTION = 2 };
+
+__device__ __forceinline__ int unpad(int i, int n, int mode)
+{
+    const int j = i - 1;
+    if (j >= 0 && j < n) return j;
+    if (mode == PAD_ZEROS) return -1;
+    if (mode == PAD_BORDER) return j < 0 ? 0 : n - 1;
+    return j < 0 ? 1 : n - 2;
+}
+
+// sparse_interpolation (core/multimodal/image.py:105-170): bilinear sampling
+// of x [B][C][H][W] at coords [n][2] = (row, column) in [0, 1], one feature map
+// per query (batch), on the map padded by one pixel.  Weights and sums are
+// float32 operations in the reference's order.
+__global__ __launch_bounds__(256) void sparse_interp_kernel(
+    const float *__restrict__ x, int C, int H, int W, const float *__restrict__ coords,
+    const i64 *__restrict__ batch, i64 rows, int mode, float *__restrict__ out)
+{
+    __shared__ float tile[64][65];
+    const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const i64 r = (i64)blockIdx.x * 64 + row;
+    const size_t hw = (size_t)H * W;
+    const float *plane = x;
+    float w_tl = 0.f, w_tr = 0.f, w_bl = 0.f, w_br = 0.f;
+    i64 o_tl = -1, o_tr = -1, o_bl = -1, o_br = -1;
+    if (r < rows) {
+        plane = x + (size_t)batch[r] * C * hw;
+        const float p0 = __fadd_rn(__fmul_rn(coords[2 * r], (float)H), 0.5f);
+        const float p1 = __fadd_rn(__fmul_rn(coords[2 * r + 1], (float)W), 0.5f);
+        const float top = floorf(p0), bottom = floorf(__fadd_rn(p0, 1.0f));
+        const float left = floorf(p1), right = floorf(__fadd_rn(p1, 1.0f));
+        w_tl = fabsf(__fmul_rn(__fsub_rn(p0, bottom), __fsub_rn(p1, right)));
+        w_tr = fabsf(__fmul_rn(__fsub_rn(p0, bottom), __fsub_rn(p1, left)));
+        w_bl = fabsf(__fmul_rn(__fsub_rn(p0, top), __fsub_rn(p1, right)));
+        w_br = fabsf(__fmul_rn(__fsub_rn(p0, top), __fsub_rn(p1, left)));
+        const int t = unpad((int)top, H, mode), b = unpad((int)bottom, H, mode);
+        const int l = unpad((int)left, W, mode), rt = unpad((int)right, W, mode);
+        if (t >= 0 && l >= 0) o_tl = (i64)t * W + l;
+        if (t >= 0 && rt >= 0) o_tr = (i64)t * W + rt;
+        if (b >= 0 && l >= 0) o_bl = (i64)b * W + l;
+        if (b >= 0 && rt >= 0) o_br = (i64)b * W + rt;
+    }
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int c = c0 + cq; c < C && c < c0 + 64; c += 4) {
+            const float *pc = plane + (size_t)c * hw;
+            const float v_tl = o_tl >= 0 ? pc[o_tl] : 0.f, v_tr = o_tr >= 0 ? pc[o_tr] : 0.f;
+            const float v_bl = o_bl >= 0 ? pc[o_bl] : 0.f, v_br = o_br >= 0 ? pc[o_br] : 0.f;
+            float acc = __fadd_rn(__fmul_rn(w_tl, v_tl), __fmul_rn(w_tr, v_tr));
+            acc = __fadd_rn(acc, __fmul_rn(w_bl, v_bl));
+            acc = __fadd_rn(acc, __fmul_rn(w_br, v_br));
+            tile[row][c - c0] = acc;
+        }
+        __syncthreads();
+        const int cw = C - c0 < 64 ? C - c0 : 64;
+        for (int e = threadIdx.x; e < 64 * cw; e += 256) {
+            const int rr = e / cw, cc = e - rr * cw;
+            const i64 ro = (i64)blockIdx.x * 64 + rr;
+            if (ro < rows) out[(size_t)ro * C + c0 + cc] = tile[rr][cc];
+        }
+        __syncthreads();
+    }
+}
+
 static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr_log)
 {
     vec = (C % 4 == 0 && ((uintptr_t)p0 % 16 == 0) && ((uintptr_t)p1 % 16 == 0)) ? 4 : 1;
@@ -364,6 +459,36 @@ extern "C" int mvf_gather_pool(
     default: MVF_GP(MVF_REDUCE_MAX); break;
     }
 #undef MVF_GP
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_gather_features(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *batch,
+    const int16_t *pixels, int64_t rows, float *out, void *stream)
+{
+    MVF_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && rows >= 0, "gather_features: bad shape");
+    if (rows == 0) return MVF_OK;
+    MVF_REQUIRE(x && batch && pixels && out, "gather_features: null pointer");
+    hipLaunchKernelGGL(gather_features_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       x, C, H, W, (const i64 *)batch, pixels, (i64)rows, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_sparse_interpolation(
+    const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const float *coords,
+    const int64_t *batch, int64_t rows, int32_t padding_mode, float *out, void *stream)
+{
+    MVF_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && rows >= 0, "sparse_interpolation: bad shape");
+    MVF_REQUIRE(padding_mode >= PAD_BORDER && padding_mode <= PAD_REFLECTION,
+                "sparse_interpolation: unknown padding mode %d", padding_mode);
+    MVF_REQUIRE(padding_mode != PAD_REFLECTION || (H >= 2 && W >= 2),
+                "sparse_interpolation: reflection padding needs H, W >= 2");
+    if (rows == 0) return MVF_OK;
+    MVF_REQUIRE(x && coords && batch && out, "sparse_interpolation: null pointer");
+    hipLaunchKernelGGL(sparse_interp_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       x, C, H, W, coords, (const i64 *)batch, (i64)rows, padding_mode, out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

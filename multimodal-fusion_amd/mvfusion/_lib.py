@@ -85,6 +85,8 @@ _SIGNATURES = {
     "mvf_segment_softmax_csr": (C.c_int, [_P, _I32, _P, _I64, _F, _I32, _P, _P]),
     "mvf_segment_csr_two_level": (C.c_int, [_P, _I64, _I32, _P, _I64, _I32, _P, _I64, _I32, _P, _I32, _P, _P]),
     "mvf_gather_pool": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P]),
+    "mvf_gather_features": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _P]),
+    "mvf_sparse_interpolation": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P]),
     "mvf_mlp_forward": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _I64, _P, _I32,
                                   _P, _I32, _P]),
     "mvf_mlp_forward_dot": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _I64, _P, _I32,

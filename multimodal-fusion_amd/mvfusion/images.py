@@ -93,6 +93,11 @@ class SameSettingImageData:
         return tuple(int(x / self.downscale) for x in self.crop_size)
 
     @property
+    def mapping_size(self):
+        """Image size the mappings refer to (image.py:656-659)."""
+        return self.crop_size
+
+    @property
     def pixel_dtype(self):
         for dtype in [torch.int16, torch.int32, torch.int64]:
             if torch.iinfo(dtype).max >= max(self.ref_size[0], self.ref_size[1]):
@@ -142,6 +147,23 @@ class SameSettingImageData:
     @property
     def mapping_features(self):
         return self.mappings.features
+
+    def get_mapped_features(self, interpolate=False):
+        """Features of ``self.x`` [V, C, H, W] at the mapped pixels, one row per
+        atomic mapping (core/multimodal/image.py:1272-1297).  Without
+        interpolation the mappings are first brought to the resolution of the
+        feature map (``1 / downscale``); with it the map is sampled bilinearly
+        at the mapping-resolution coordinates."""
+        from . import pooling
+        scale = 1 / self.downscale
+        mappings = self.mappings if interpolate else self.mappings.rescale_images(scale)
+        if interpolate and scale != 1:
+            resolution = torch.Tensor([self.mapping_size]).to(mappings.pixels.device)
+            coords = mappings.pixels / (resolution - 1)
+            coords = coords[:, [1, 0]]       # pixel mappings are (W, H)
+            batch = mappings.feature_map_indexing[0]
+            return pooling.sparse_interpolation(self.x, coords, batch)
+        return pooling.gather_features(self.x, mappings)
 
     def __repr__(self):
         return f"{self.__class__.__name__}(num_views={self.num_views}, " \

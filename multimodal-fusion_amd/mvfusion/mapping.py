@@ -178,6 +178,52 @@ class ImageMapping(CSRData):
             point_ids[keep], image_ids[keep], pixels[keep],
             features[keep] if features is not None else None, num_points=int(idx.max()) + 1)
 
+    def rescale_images(self, ratio):
+        """Mappings at a new image resolution: downscaled when ``ratio < 1``,
+        upscaled otherwise (core/multimodal/image.py:1911-1924).  Returns a new
+        ImageMapping."""
+        if ratio < 1:
+            return self.downscale_images(1 / ratio)
+        return self.upscale_images(ratio)
+
+    def _with_pixels(self, pixels):
+        """Copy of self whose nested pixel CSR holds ``pixels`` (the pointer and
+        value tensors of the other levels are shared)."""
+        out = self.clone()
+        nested = self.values[1].clone()
+        nested.values[0] = pixels
+        out.values[1] = nested
+        return out
+
+    def downscale_images(self, ratio):
+        """Pixel coordinates floor-divided by ``ratio >= 1``
+        (core/multimodal/image.py:1926-1990).  The reference de-duplicates on
+        (atomic row id, x, y); row ids are distinct, so every row is kept and
+        the nested pointers do not change."""
+        assert ratio >= 1, \
+            f"Invalid image subsampling ratio: {ratio}. Must be larger than 1."
+        if ratio == 1:
+            return self.clone()
+        pix = self.pixels
+        return self._with_pixels((pix // ratio).long().type(pix.dtype))
+
+    def upscale_images(self, ratio, center=True):
+        """Pixel coordinates multiplied by ``ratio >= 1``; with ``center`` the
+        high-resolution pixel closest to the centre of the low-resolution one
+        (core/multimodal/image.py:1992-2037).  Unlike the reference, whose
+        shallow clone shares the nested pixel CSR with its source and therefore
+        rescales the source too, the result here is independent of ``self``."""
+        assert ratio >= 1, \
+            f"Invalid image upsampling ratio: {ratio}. Must be larger than 1."
+        if ratio == 1:
+            return self.clone()
+        pix = self.pixels
+        if center:
+            up = (pix.float() * ratio + ratio / 2).long()
+        else:
+            up = (pix.float() * ratio).long()
+        return self._with_pixels(up.type(pix.dtype))
+
     def debug(self):
         super(ImageMapping, self).debug()
         assert len(self.values) == 2 or self.has_features

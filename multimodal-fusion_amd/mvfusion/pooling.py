@@ -167,6 +167,69 @@ def gather_atomic_pool(x, mappings, mode='max'):
     return out
 
 
+def gather_features(x, mappings):
+    """``x[mappings.feature_map_indexing]`` for a [B, C, H, W] batch of feature
+    maps (core/multimodal/image.py:1295, 1881-1895): one row of C features per
+    mapped pixel."""
+    if not x.is_cuda:
+        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise TypeError("gather_features expects a float32 [B, C, H, W] feature map")
+    dev = x.device
+    x = x.detach().contiguous()
+    images = mappings.images.to(dev, torch.int64)
+    pixels = mappings.pixels.to(dev, torch.int16).contiguous()
+    rows = pixels.shape[0]
+    B, C_, H, W = x.shape
+    if rows and (int(images.max()) >= B or int(pixels[:, 0].max()) >= W or int(pixels[:, 1].max()) >= H
+                 or int(pixels.min()) < 0 or int(images.min()) < 0):
+        raise IndexError("mappings index outside the feature map")
+    batch = mappings.feature_map_indexing[0].to(dev).contiguous()
+    out = torch.empty((rows, C_), dtype=torch.float32, device=dev)
+    if rows:
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_gather_features(
+                L.ptr(x), B, C_, H, W, L.ptr(batch), L.ptr(pixels), rows, L.ptr(out),
+                L.stream_ptr(dev)))
+    return out
+
+
+_PADDING = {'border': 0, 'zeros': 1, 'reflection': 2}
+
+
+def sparse_interpolation(features, coords, batch, padding_mode='border'):
+    """Bilinear interpolation of a batch of feature maps [B, C, H, W] at the
+    [N, 2] coordinates ``coords`` (row, column, both in [0, 1]) of the maps
+    ``batch`` [N] (core/multimodal/image.py:105-170).  Returns [N, C]."""
+    assert len(features.shape) == 4
+    assert coords.shape[0] == batch.shape[0]
+    assert len(coords.shape) == 2 and coords.shape[1] == 2
+    if padding_mode not in _PADDING:
+        raise NotImplementedError(f"Unknown padding_mode='{padding_mode}'")
+    if not features.is_cuda:
+        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
+    dev = features.device
+    x = features.detach().float().contiguous()
+    coords = coords.to(dev, torch.float32).contiguous()
+    batch = batch.to(dev, torch.int64).contiguous()
+    n = coords.shape[0]
+    B, C_, H, W = x.shape
+    if n:
+        assert 0 <= coords.min()
+        assert coords.max() <= 1
+        if int(batch.max()) >= B or int(batch.min()) < 0:
+            raise IndexError("batch index outside the feature maps")
+    out = torch.empty((n, C_), dtype=torch.float32, device=dev)
+    if n:
+        lib = L.load()
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_sparse_interpolation(
+                L.ptr(x), B, C_, H, W, L.ptr(coords), L.ptr(batch), n, _PADDING[padding_mode],
+                L.ptr(out), L.stream_ptr(dev)))
+    return out
+
+
 def group_sizes(num_elements, num_groups):
     """pooling.py:749-757."""
     sizes = torch.full(

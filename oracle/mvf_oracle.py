@@ -681,6 +681,57 @@ def select_points(m, idx, mode="pick"):
     return mapping_from_dense(point_ids[u], image_ids[u], pix[u], mean[u], num_points=int(idx.max()) + 1)
 
 
+def downscale_pixels(pixels, ratio):
+    """ImageMapping.downscale_images, core/multimodal/image.py:1926-1990: the
+    de-duplication key starts with the (distinct) atomic row id, so every row
+    survives and only the coordinates change."""
+    pixels = np.asarray(pixels)
+    if ratio == 1:
+        return pixels.copy()
+    return np.floor(pixels / np.float32(ratio)).astype(np.int64).astype(pixels.dtype)
+
+
+def upscale_pixels(pixels, ratio, center=True):
+    """ImageMapping.upscale_images, core/multimodal/image.py:1992-2037."""
+    pixels = np.asarray(pixels)
+    if ratio == 1:
+        return pixels.copy()
+    up = pixels.astype(np.float32) * np.float32(ratio)
+    if center:
+        up = up + np.float32(ratio / 2)
+    return up.astype(np.int64).astype(pixels.dtype)
+
+
+def feature_map_batch(images, view_ptr):
+    """first entry of ImageMapping.feature_map_indexing, image.py:1890-1891"""
+    return np.repeat(np.asarray(images, np.int64), np.diff(np.asarray(view_ptr, np.int64)))
+
+
+def gather_features(x, images, view_ptr, pixels):
+    """X[mappings.feature_map_indexing], core/multimodal/image.py:1295,1881-1895."""
+    pixels = np.asarray(pixels).astype(np.int64)
+    return x[feature_map_batch(images, view_ptr), :, pixels[:, 1], pixels[:, 0]]
+
+
+def sparse_interpolation(features, coords, batch, padding_mode="border"):
+    """sparse_interpolation, core/multimodal/image.py:105-170 (float32)."""
+    mode = {"zeros": "constant", "border": "edge", "reflection": "reflect"}[padding_mode]
+    pad = np.pad(features, ((0, 0), (0, 0), (1, 1), (1, 1)), mode=mode)
+    h, w = features.shape[2:]
+    f32 = np.float32
+    pix = np.asarray(coords, f32) * np.array([[h, w]], f32) + f32(0.5)
+    top, bottom = np.floor(pix[:, 0]), np.floor(pix[:, 0] + f32(1))
+    left, right = np.floor(pix[:, 1]), np.floor(pix[:, 1] + f32(1))
+    corner = lambda a, b: np.stack([a, b], 1).astype(np.int64)
+    tl, tr, bl, br = corner(top, left), corner(top, right), corner(bottom, left), corner(bottom, right)
+    wgt = lambda c: np.abs(np.prod(pix - c.astype(f32), axis=1, dtype=f32))[:, None]
+    at = lambda c: pad[batch, :, c[:, 0], c[:, 1]]
+    out = wgt(br) * at(tl) + wgt(bl) * at(tr)
+    out = out + wgt(tr) * at(bl)
+    out = out + wgt(tl) * at(br)
+    return out.astype(f32)
+
+
 def pixel_dtype(ref_size):
     """SameSettingImageData.pixel_dtype, core/multimodal/image.py:507-516."""
     for dt in (np.int16, np.int32, np.int64):

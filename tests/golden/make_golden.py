@@ -351,6 +351,56 @@ def gen_from_dense():
          **arrs)
 
 
+# ----------------------------------------------------------- mapped features
+def gen_mapped_features():
+    """What SameSettingImageData.get_mapped_features (core/multimodal/image.py:
+    1272-1297) is made of: ImageMapping.rescale_images / downscale_images /
+    upscale_images (:1911-2037), feature_map_indexing (:1881-1895) on a
+    [B, C, H, W] feature map, and sparse_interpolation (:105-170)."""
+    image = ref["image"]
+    rng = np.random.default_rng(31)
+    P, n_pts, n_img = 4000, 500, 5
+    Wm, Hm = 96, 64                                   # mapping size (W, H)
+    pid = rng.integers(0, n_pts - 30, P)
+    iid = rng.integers(0, n_img, P)
+    pix = np.stack([rng.integers(0, Wm, P), rng.integers(0, Hm, P)], 1).astype(np.int16)
+    feat = rng.random((P, 2)).astype(np.float32)
+    fresh = lambda: image.ImageMapping.from_dense(
+        T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
+    m = fresh()
+    # the mapping's own arrays: the order of the pixels inside a view depends on
+    # an unstable sort, so consumers start from these rather than from_dense
+    arrs = dict(num_points=n_pts, mapping_size=np.array([Wm, Hm]),
+                pointers=m.pointers.numpy(), images=m.images.numpy(),
+                view_pointers=m.values[1].pointers.numpy(), pixels=m.pixels.numpy(),
+                features=m.features.numpy())
+    # feature maps at the mapping resolution and at half of it
+    x1 = rng.random((n_img, 7, Hm, Wm)).astype(np.float32)
+    x2 = rng.random((n_img, 7, Hm // 2, Wm // 2)).astype(np.float32)
+    arrs.update(x1=x1, x2=x2)
+    # interpolate=False: mappings rescaled to the feature map, then x[idx]
+    arrs["gather_scale1"] = T(x1)[m.rescale_images(1).feature_map_indexing].numpy()
+    down = m.rescale_images(1 / 2)
+    arrs["down_pixels"] = down.pixels.numpy()
+    arrs["down_view_pointers"] = down.values[1].pointers.numpy()
+    arrs["gather_scale_half"] = T(x2)[down.feature_map_indexing].numpy()
+    for center in (True, False):
+        # on a fresh mapping: the reference's upscale_images writes the new
+        # pixels into the nested CSR it shares with its source (shallow clone)
+        up = fresh().upscale_images(2, center=center)
+        arrs[f"up_pixels_center{int(center)}"] = up.pixels.numpy()
+    # interpolate=True with scale != 1 (:1288-1293)
+    resolution = torch.Tensor([[Wm, Hm]])
+    coords = (m.pixels / (resolution - 1))[:, [1, 0]]
+    batch = m.feature_map_indexing[0]
+    arrs["coords"] = coords.numpy()
+    arrs["batch"] = batch.numpy()
+    for mode in ("border", "zeros", "reflection"):
+        arrs["interp_" + mode] = image.sparse_interpolation(
+            T(x2), coords, batch, padding_mode=mode).numpy()
+    save("mapped_features", **arrs)
+
+
 # ------------------------------------------------------------- select_points
 def gen_select_points():
     """ImageMapping.select_points (core/multimodal/image.py:2177-2287), the CSR
@@ -551,6 +601,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "select_points", "pooling", "attention_pools", "attention_variants"]
+        "from_dense", "mapped_features", "select_points", "pooling", "attention_pools", "attention_variants"]
     for w in which:
         globals()["gen_" + w]()

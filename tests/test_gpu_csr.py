@@ -161,3 +161,84 @@ def test_select_points_golden(golden, mode):
     if mode == "merge":
         bad = m.select_points(T(g["merge"][:-1]), mode="merge")      # wrong length: unchanged
         assert torch.equal(bad.pointers, m.pointers)
+
+
+# ----------------------------------------------------------- mapped features
+def _mapping_from_fixture(g):
+    return M.ImageMapping.from_csr_arrays(
+        T(g["pointers"]).cuda(), T(g["images"]).cuda(), T(g["pixels"]).cuda(),
+        T(g["features"]).cuda(), view_pointers=T(g["view_pointers"]).cuda())
+
+
+def test_mapped_features_golden(golden):
+    """get_mapped_features and its parts against the reference's outputs:
+    gathers bit-exact, bilinear interpolation to 1e-6 relative."""
+    from mvfusion import pooling as P
+    from mvfusion.images import SameSettingImageData
+    g = golden("mapped_features")
+    m = _mapping_from_fixture(g)
+    x1, x2 = T(g["x1"]).cuda(), T(g["x2"]).cuda()
+    assert np.array_equal(P.gather_features(x1, m).cpu().numpy(), g["gather_scale1"])
+    down = m.rescale_images(1 / 2)
+    assert down.pixels.dtype == torch.int16
+    assert np.array_equal(down.pixels.cpu().numpy(), g["down_pixels"])
+    assert np.array_equal(down.values[1].pointers.cpu().numpy(), g["down_view_pointers"])
+    assert np.array_equal(P.gather_features(x2, down).cpu().numpy(), g["gather_scale_half"])
+    for center in (True, False):
+        up = m.upscale_images(2, center=center)
+        assert np.array_equal(up.pixels.cpu().numpy(), g[f"up_pixels_center{int(center)}"])
+    # the source mapping is left as it was
+    assert np.array_equal(m.pixels.cpu().numpy(), g["pixels"])
+    coords, batch = T(g["coords"]).cuda(), T(g["batch"]).cuda()
+    for mode in ("border", "zeros", "reflection"):
+        got = P.sparse_interpolation(x2, coords, batch, padding_mode=mode).cpu().numpy()
+        np.testing.assert_allclose(got, g["interp_" + mode], rtol=1e-6, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        P.sparse_interpolation(x2, coords, batch, padding_mode="nope")
+    # the container method: maps at the mapping resolution, at half of it
+    # (mappings rescaled) and at half of it with interpolation
+    n_img = g["x1"].shape[0]
+    Wm, Hm = (int(v) for v in g["mapping_size"])
+    for x, downscale, interpolate, want in (
+            (x1, 1, False, g["gather_scale1"]), (x2, 2, False, g["gather_scale_half"]),
+            (x2, 2, True, g["interp_border"])):
+        images = SameSettingImageData(pos=torch.zeros(n_img, 3), ref_size=(Wm, Hm),
+                                      proj_upscale=1, downscale=downscale, x=x, mappings=m)
+        got = images.get_mapped_features(interpolate=interpolate).cpu().numpy()
+        if interpolate:
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+        else:
+            assert np.array_equal(got, want)
+
+
+def test_gather_features_and_interpolation_vs_oracle_large():
+    """C=64 feature maps, 300k mapped pixels: the gather is a pure copy
+    (bit-exact), the interpolation follows the oracle's float32 order."""
+    import mvf_oracle as orc
+    from mvfusion import pooling as P
+    rng = np.random.default_rng(41)
+    B, C, H, W, n_views = 6, 64, 188, 352, 60000
+    sizes = rng.integers(1, 10, n_views)
+    vptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(vptr[-1])
+    images = rng.integers(0, B, n_views).astype(np.int64)
+    pixels = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1).astype(np.int16)
+    x = rng.random((B, C, H, W)).astype(np.float32)
+    ptr = np.arange(n_views + 1, dtype=np.int64)
+    m = M.ImageMapping.from_csr_arrays(
+        T(ptr).cuda(), T(images).cuda(), T(pixels).cuda(), None, view_pointers=T(vptr).cuda())
+    got = P.gather_features(T(x).cuda(), m).cpu().numpy()
+    assert np.array_equal(got, orc.gather_features(x, images, vptr, pixels))
+    batch = orc.feature_map_batch(images, vptr)
+    coords = rng.random((n, 2)).astype(np.float32)
+    coords[:50] = 0.0
+    coords[50:100] = 1.0
+    for mode in ("border", "zeros", "reflection"):
+        got = P.sparse_interpolation(T(x).cuda(), T(coords).cuda(), T(batch).cuda(), mode)
+        want = orc.sparse_interpolation(x, coords, batch, mode)
+        assert np.array_equal(got.cpu().numpy(), want), mode
+    with pytest.raises(IndexError):
+        bad = M.ImageMapping.from_csr_arrays(
+            T(ptr).cuda(), T(images + B).cuda(), T(pixels).cuda(), None,
+            view_pointers=T(vptr).cuda())
+        P.gather_features(T(x).cuda(), bad)

@@ -156,6 +156,31 @@ def test_from_dense(golden):
     np.testing.assert_allclose(m["features"], g["out_features"], rtol=1e-6, atol=1e-7)
 
 
+def test_mapped_features(golden):
+    """rescale_images + feature_map_indexing gather + sparse_interpolation, the
+    parts of SameSettingImageData.get_mapped_features."""
+    g = golden("mapped_features")
+    m = g
+    got = orc.gather_features(g["x1"], m["images"], m["view_pointers"], m["pixels"])
+    assert np.array_equal(got, g["gather_scale1"])
+    down = orc.downscale_pixels(m["pixels"], 2.0)
+    assert down.dtype == g["down_pixels"].dtype and np.array_equal(down, g["down_pixels"])
+    assert np.array_equal(m["view_pointers"], g["down_view_pointers"])
+    got = orc.gather_features(g["x2"], m["images"], m["view_pointers"], down)
+    assert np.array_equal(got, g["gather_scale_half"])
+    for center in (True, False):
+        assert np.array_equal(orc.upscale_pixels(m["pixels"], 2, center),
+                              g[f"up_pixels_center{int(center)}"])
+    batch = orc.feature_map_batch(m["images"], m["view_pointers"])
+    assert np.array_equal(batch, g["batch"])
+    res = np.array([g["mapping_size"]], np.float32)
+    coords = (m["pixels"].astype(np.float32) / (res - 1))[:, [1, 0]]
+    assert np.array_equal(coords, g["coords"])
+    for mode in ("border", "zeros", "reflection"):
+        got = orc.sparse_interpolation(g["x2"], coords, batch, mode)
+        np.testing.assert_allclose(got, g["interp_" + mode], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("mode", ["pick", "merge"])
 def test_select_points(golden, mode):
     g = golden("select_points")
