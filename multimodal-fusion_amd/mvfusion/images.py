@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .csr import tensor_idx
-from .mapping import ImageMapping
+from .mapping import ImageMapping, ImageMappingBatch
 
 
 class SameSettingImageData:
@@ -54,6 +54,41 @@ class SameSettingImageData:
         return self.pos.device
 
     _fisheye_keys = ('xi', 'k1', 'k2', 'gamma1', 'gamma2', 'u0', 'v0')
+    _pinhole_keys = ('fx', 'fy', 'mx', 'my')
+    # per-view attributes (concatenated by a batch) / attributes all views share
+    _torch_keys = ('pos', 'opk', 'extrinsic', 'crop_offsets') + _pinhole_keys + _fisheye_keys
+    _shared_keys = ('ref_size', 'proj_upscale', 'downscale', 'crop_size', 'mask', 'visibility')
+
+    def to_dict(self):
+        """Constructor arguments of self (core/multimodal/image.py:395-397)."""
+        keys = ('path',) + self._torch_keys + self._shared_keys + ('mappings', 'x')
+        return {k: getattr(self, k) for k in keys}
+
+    @property
+    def settings_hash(self):
+        """Identifier of the settings every view shares, mask and visibility
+        model aside: only images with equal hashes can be batched together
+        (core/multimodal/image.py:1217-1229)."""
+        keys = ('ref_size', 'proj_upscale', 'downscale', 'crop_size')
+        return hash(tuple(getattr(self, k) for k in keys))
+
+    @staticmethod
+    def get_batch_type():
+        return SameSettingImageBatch
+
+    def clone(self):
+        """Shallow copy, except for x and mappings (image.py:1174-1183)."""
+        out = copy.copy(self)
+        out.x = self.x.clone() if self.x is not None else None
+        out.mappings = self.mappings.clone() if self.mappings is not None else None
+        return out
+
+    def to(self, device):
+        out = copy.copy(self)
+        for k in self._torch_keys + ('x', 'mappings', 'mask'):
+            v = getattr(self, k)
+            setattr(out, k, v.to(device) if v is not None else None)
+        return out
 
     @property
     def has_opk(self):
@@ -114,9 +149,7 @@ class SameSettingImageData:
     def __getitem__(self, idx):
         idx = tensor_idx(idx).to(self.device)
         assert idx.unique().numel() == idx.shape[0], "Index must not contain duplicates."
-        assert self.mappings is None, \
-            "view selection of an already-mapped SameSettingImageData is not supported here"
-        sel = lambda t: t[idx] if t is not None else None
+        sel = lambda t: t[idx.to(t.device)] if t is not None else None
         return self.__class__(
             path=self.path[np.asarray(idx.cpu())], pos=self.pos[idx],
             extrinsic=sel(self.extrinsic), fx=sel(self.fx), fy=sel(self.fy),
@@ -124,7 +157,9 @@ class SameSettingImageData:
             proj_upscale=copy.deepcopy(self.proj_upscale),
             downscale=copy.deepcopy(self.downscale),
             crop_size=copy.deepcopy(self.crop_size), crop_offsets=self.crop_offsets[idx],
-            x=sel(self.x), mask=self.mask.clone() if self.mask is not None else None,
+            x=sel(self.x),
+            mappings=self.mappings.select_images(idx) if self.mappings is not None else None,
+            mask=self.mask.clone() if self.mask is not None else None,
             visibility=copy.deepcopy(self.visibility), opk=sel(self.opk),
             **{a: sel(getattr(self, a)) for a in self._fisheye_keys})
 
@@ -170,12 +205,82 @@ class SameSettingImageData:
                f"num_points={self.num_points}, device={self.device})"
 
 
+class SameSettingImageBatch(SameSettingImageData):
+    """Concatenation of SameSettingImageData items that refer to different
+    point clouds: per-view attributes and feature maps are concatenated, the
+    mappings become an ImageMappingBatch whose point ids follow the order of
+    the items (core/multimodal/image.py:1300-1416)."""
+
+    def __init__(self, **kwargs):
+        super(SameSettingImageBatch, self).__init__(**kwargs)
+        self.__sizes__ = None
+
+    @property
+    def batch_pointers(self):
+        return np.cumsum(np.concatenate(([0], self.__sizes__))) \
+            if self.__sizes__ is not None else None
+
+    @property
+    def batch_items_sizes(self):
+        return self.__sizes__ if self.__sizes__ is not None else None
+
+    @property
+    def num_batch_items(self):
+        return len(self.__sizes__) if self.__sizes__ is not None else None
+
+    @staticmethod
+    def from_data_list(image_data_list):
+        assert isinstance(image_data_list, list) and len(image_data_list) > 0
+        assert all(isinstance(x, SameSettingImageData) for x in image_data_list)
+        first = image_data_list[0]
+        hash_ref = first.settings_hash
+        assert all(im.settings_hash == hash_ref for im in image_data_list), \
+            f"All SameSettingImageData values for shared keys " \
+            f"{SameSettingImageData._shared_keys} must be the same (except for the 'mask')."
+        # shared attributes (and the mask) come from the first item
+        batch_dict = {k: getattr(first, k) for k in SameSettingImageData._shared_keys}
+        batch_dict['path'] = np.concatenate([im.path for im in image_data_list])
+        for key in SameSettingImageData._torch_keys:
+            vals = [getattr(im, key) for im in image_data_list]
+            batch_dict[key] = None if any(v is None for v in vals) else torch.cat(vals)
+        xs = [im.x for im in image_data_list]
+        batch_dict['x'] = None if any(x is None for x in xs) else torch.cat(xs)
+        maps = [im.mappings for im in image_data_list]
+        batch_dict['mappings'] = None if any(m is None for m in maps) \
+            else ImageMappingBatch.from_csr_list(maps)
+        batch = SameSettingImageBatch(**batch_dict)
+        batch.__sizes__ = np.array([im.num_views for im in image_data_list])
+        return batch
+
+    def to_data_list(self):
+        if self.__sizes__ is None:
+            raise RuntimeError(
+                'Cannot reconstruct image data list from batch because the batch object was '
+                'not created using `SameSettingImageBatch.from_data_list()`.')
+        ptr = self.batch_pointers
+        items = []
+        for i in range(self.num_batch_items):
+            idx = torch.arange(int(ptr[i]), int(ptr[i + 1]))
+            item = SameSettingImageData.__getitem__(self, idx)
+            items.append(SameSettingImageData(**item.to_dict()))
+        return items
+
+
 class ImageData:
     """List of SameSettingImageData with different settings
     (core/multimodal/image.py:1419-1606), as far as transforms need it."""
 
     def __init__(self, image_list):
         self._list = list(image_list)
+
+    @property
+    def num_points(self):
+        """Number of points the mappings refer to (0 when there is no image)."""
+        return self._list[0].num_points if len(self._list) > 0 else 0
+
+    @staticmethod
+    def get_batch_type():
+        return ImageBatch
 
     def __len__(self):
         return len(self._list)
@@ -185,3 +290,69 @@ class ImageData:
 
     def __iter__(self):
         return iter(self._list)
+
+
+class ImageBatch(ImageData):
+    """Batch of ImageData: images with equal settings are concatenated into one
+    SameSettingImageBatch each, and every mapping is re-based on the
+    concatenated point cloud of all items (core/multimodal/image.py:1608-1735).
+    Settings groups are kept in order of first appearance."""
+
+    def __init__(self, image_list):
+        super(ImageBatch, self).__init__(image_list)
+        self.__il_sizes__ = None
+        self.__hashes__ = None
+        self.__il_idx_dict__ = None
+        self.__im_idx_dict__ = None
+        self.__cum_pts__ = None
+
+    @staticmethod
+    def from_data_list(image_data_list):
+        assert isinstance(image_data_list, list) and len(image_data_list) > 0
+        assert all(isinstance(x, ImageData) for x in image_data_list)
+        hashes = []
+        for il in image_data_list:
+            for im in il:
+                if im.settings_hash not in hashes:
+                    hashes.append(im.settings_hash)
+        n_pts = torch.LongTensor([il.num_points for il in image_data_list])
+        cum_pts = torch.cumsum(torch.cat((torch.LongTensor([0]), n_pts)), dim=0)
+        il_sizes = [len(il) for il in image_data_list]
+        il_idx_dict = {h: [] for h in hashes}
+        im_idx_dict = {h: [] for h in hashes}
+        groups = {h: [] for h in hashes}
+        for il_idx, il in enumerate(image_data_list):
+            for im_idx, im in enumerate(il):
+                h = im.settings_hash
+                il_idx_dict[h].append(il_idx)
+                im_idx_dict[h].append(im_idx)
+                groups[h].append(im)
+        batches = [SameSettingImageBatch.from_data_list(groups[h]) for h in hashes]
+        # mappings of a settings group only know the points of the items that
+        # hold such images: insert the other items' points as empty groups
+        for h, im in zip(hashes, batches):
+            if im.num_points > 0:
+                global_idx = torch.cat(
+                    [torch.arange(int(cum_pts[i]), int(cum_pts[i + 1])) for i in il_idx_dict[h]])
+                im.mappings.insert_empty_groups(
+                    global_idx.to(im.mappings.device), num_groups=int(cum_pts[-1]))
+        out = ImageBatch(batches)
+        out.__il_sizes__ = il_sizes
+        out.__hashes__ = hashes
+        out.__il_idx_dict__ = il_idx_dict
+        out.__im_idx_dict__ = im_idx_dict
+        out.__cum_pts__ = cum_pts
+        return out
+
+    def to_data_list(self):
+        assert self.__il_sizes__ is not None, \
+            "Cannot reconstruct the list of ImageData because the ImageBatch was not " \
+            "created using 'ImageBatch.from_data_list'."
+        out = [[None] * s for s in self.__il_sizes__]
+        for h, ib in zip(self.__hashes__, self):
+            for il_idx, im_idx, im in zip(
+                    self.__il_idx_dict__[h], self.__im_idx_dict__[h], ib.to_data_list()):
+                start, end = int(self.__cum_pts__[il_idx]), int(self.__cum_pts__[il_idx + 1])
+                im.mappings = im.mappings[torch.arange(start, end)]
+                out[il_idx][im_idx] = im
+        return [ImageData(x) for x in out]

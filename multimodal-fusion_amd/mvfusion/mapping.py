@@ -7,6 +7,7 @@ Layout (all on one device):
 ``values[1]`` = CSRData{``pointers`` int64 [Vw+1] view -> pixels, ``values[0]`` =
 ``pixels`` [P, 2] (x, y)}; ``values[2]`` = ``features`` float32 [Vw, F].
 """
+import numpy as np
 import torch
 
 from .csr import CSRData, CSRBatch, tensor_idx
@@ -118,6 +119,66 @@ class ImageMapping(CSRData):
                                 is_index_value=[True, False])
         return ImageMapping(pointers, images, nested, features, dense=False,
                             is_index_value=[True, False, False])
+
+    def _from_kept_views(self, keep, values):
+        """Mapping made of the views selected by ``keep`` (index or mask over
+        the view-level rows): pointers rebuilt from the surviving views' point
+        ids, empty points re-inserted (core/multimodal/image.py:2084-2099)."""
+        sizes = self.pointers[1:] - self.pointers[:-1]
+        point_ids = torch.arange(self.num_groups, device=self.device).repeat_interleave(sizes)
+        point_ids = point_ids[keep]
+        pointers = CSRData._sorted_indices_to_pointers(point_ids)
+        out = self.__class__(pointers, *values, dense=False, is_index_value=self.is_index_value)
+        point_ids = point_ids[out.pointers[1:] - 1]
+        return out.insert_empty_groups(point_ids, num_groups=self.num_groups)
+
+    def select_images(self, idx):
+        """Keep the mappings to the images ``idx`` (no duplicates) and renumber
+        them idx[i] -> i (core/multimodal/image.py:2039-2103)."""
+        idx = tensor_idx(idx).to(self.device)
+        assert idx.unique().numel() == idx.shape[0], "Index must not contain duplicates."
+        if self.num_items == 0:
+            return self.clone()
+        view_idx = torch.where((self.images[..., None] == idx).any(-1))[0]
+        values = [val[view_idx] for val in self.values]
+        if idx.shape[0] == 0:
+            return self.__class__(torch.zeros_like(self.pointers), *values, dense=False,
+                                  is_index_value=self.is_index_value)
+        idx_gen = torch.full((int(idx.max()) + 1,), -1, dtype=torch.int64, device=self.device)
+        idx_gen = idx_gen.scatter_(0, idx, torch.arange(idx.shape[0], device=self.device))
+        values[0] = idx_gen[values[0]]
+        if view_idx.shape[0] == 0:
+            return self.__class__(torch.zeros_like(self.pointers), *values, dense=False,
+                                  is_index_value=self.is_index_value)
+        return self._from_kept_views(view_idx, values)
+
+    def select_views(self, view_mask):
+        """Keep the views of the boolean ``view_mask`` and renumber the images
+        that are left; returns (mapping, kept image indices or None when all
+        images remain) (core/multimodal/image.py:2105-2175)."""
+        if isinstance(view_mask, np.ndarray):
+            view_mask = torch.from_numpy(view_mask)
+        assert view_mask.dtype == torch.bool and view_mask.dim() == 1 \
+            and view_mask.shape[0] == self.num_items, \
+            f"view_mask must be a torch.BoolTensor of size {self.num_items}."
+        if self.num_items == 0:
+            return self.clone()
+        view_mask = view_mask.to(self.device)
+        values = [val[view_mask] for val in self.values]
+        if not torch.any(view_mask):
+            out = self.__class__(torch.zeros_like(self.pointers), *values, dense=False,
+                                 is_index_value=self.is_index_value)
+            return out, torch.LongTensor([])
+        img_idx = values[0].unique()
+        if img_idx.numel() < int(self.images.max()) + 1:
+            idx_gen = torch.full((int(img_idx.max()) + 1,), -1, dtype=torch.int64,
+                                 device=self.device)
+            idx_gen = idx_gen.scatter_(
+                0, img_idx, torch.arange(img_idx.shape[0], device=self.device))
+            values[0] = idx_gen[values[0]]
+        else:
+            img_idx = None
+        return self._from_kept_views(view_mask, values), img_idx
 
     def select_points(self, idx, mode='pick'):
         """Update the 3D points sampling (core/multimodal/image.py:2177-2287):

@@ -401,6 +401,76 @@ def gen_mapped_features():
     save("mapped_features", **arrs)
 
 
+# ------------------------------------------------------------- image batches
+def mapping_arrays(m, prefix):
+    out = {prefix + "pointers": m.pointers.numpy(), prefix + "images": m.images.numpy(),
+           prefix + "view_pointers": m.values[1].pointers.numpy(),
+           prefix + "pixels": m.pixels.numpy()}
+    if m.has_features:
+        out[prefix + "features"] = m.features.numpy()
+    return out
+
+
+def gen_image_batch():
+    """SameSettingImageBatch / ImageBatch collation and ImageMapping.select_images /
+    select_views (core/multimodal/image.py:1300-1416, 1608-1735, 2039-2175)."""
+    image = ref["image"]
+
+    def item(n_pts, n_img, P, seed, size):
+        r = np.random.default_rng(seed)
+        pid = r.integers(0, n_pts - 5, P)
+        iid = np.concatenate([np.arange(n_img), r.integers(0, n_img, P - n_img)])
+        pix = r.integers(0, size, (P, 2)).astype(np.int16)
+        feat = r.random((P, 2)).astype(np.float32)
+        m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
+        f32 = lambda *shape: T(r.random(shape).astype(np.float32))
+        return image.SameSettingImageData(
+            path=np.array([f"s{seed}_{i}" for i in range(n_img)], dtype='O'),
+            pos=T(r.random((n_img, 3))), extrinsic=f32(n_img, 4, 4), fx=f32(n_img),
+            fy=f32(n_img), mx=f32(n_img), my=f32(n_img), ref_size=(size, size),
+            proj_upscale=1, downscale=1, mappings=m, x=f32(n_img, 3, size, size))
+
+    # three samples; each has images of two settings (64 px and 32 px)
+    n_pts = [50, 70, 40]
+    big = [item(n, k, P, 10 + i, 64) for i, (n, k, P) in enumerate(zip(n_pts, [3, 4, 2], [200, 300, 150]))]
+    small = [item(n, k, P, 20 + i, 32) for i, (n, k, P) in enumerate(zip(n_pts, [2, 2, 3], [90, 120, 100]))]
+    arrs = dict(n_pts=np.array(n_pts))
+    for tag, items in (("big", big), ("small", small)):
+        for i, im in enumerate(items):
+            arrs.update(mapping_arrays(im.mappings, f"{tag}{i}_"))
+            arrs[f"{tag}{i}_pos"] = im.pos.numpy()
+            arrs[f"{tag}{i}_x"] = im.x.numpy()
+    b = image.SameSettingImageBatch.from_data_list(big)
+    arrs.update(mapping_arrays(b.mappings, "ssb_"))
+    arrs.update(ssb_pos=b.pos.numpy(), ssb_x=b.x.numpy(), ssb_sizes=b.batch_items_sizes,
+                ssb_path=np.array([str(p) for p in b.path]))
+    arrs.update(mapping_arrays(b.to_data_list()[1].mappings, "ssb_item1_"))
+    # select_images / select_views on the second sample's mapping
+    m = big[1].mappings
+    sel = np.array([2, 0], np.int64)
+    arrs["sel_idx"] = sel
+    arrs.update(mapping_arrays(m.select_images(T(sel)), "sel_"))
+    mask = np.random.default_rng(5).random(m.num_items) < 0.5
+    mask[m.images.numpy() == 1] = False          # image 1 loses all its views
+    out, img_idx = m.select_views(T(mask))
+    arrs["view_mask"] = mask
+    arrs["views_img_idx"] = img_idx.numpy()
+    arrs.update(mapping_arrays(out, "views_"))
+    # ImageBatch: [big_i, small_i] per sample
+    ib = image.ImageBatch.from_data_list([image.ImageData([a, c]) for a, c in zip(big, small)])
+    for k, ssb in enumerate(ib):
+        arrs[f"ib{k}_ref_size"] = np.array(ssb.ref_size)
+        arrs[f"ib{k}_pos"] = ssb.pos.numpy()
+        arrs.update(mapping_arrays(ssb.mappings, f"ib{k}_"))
+    back = ib.to_data_list()
+    for i, il in enumerate(back):
+        for k, im in enumerate(il):
+            src = (big, small)[k][i]
+            assert torch.equal(im.mappings.pointers, src.mappings.pointers)
+            assert torch.equal(im.mappings.pixels, src.mappings.pixels)
+    save("image_batch", **arrs)
+
+
 # ------------------------------------------------------------- select_points
 def gen_select_points():
     """ImageMapping.select_points (core/multimodal/image.py:2177-2287), the CSR
@@ -601,6 +671,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "select_points", "pooling", "attention_pools", "attention_variants"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants"]
     for w in which:
         globals()["gen_" + w]()

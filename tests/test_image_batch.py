@@ -1,0 +1,103 @@
+"""Collation of images and mappings into per-GPU batches, and the view / image
+selections of ImageMapping, against outputs of the reference's own classes
+(fixture image_batch.npz).  Host logic on index tensors: runs without a GPU."""
+import numpy as np
+import torch
+
+from mvfusion.images import ImageBatch, ImageData, SameSettingImageBatch, SameSettingImageData
+from mvfusion.mapping import ImageMapping, ImageMappingBatch
+
+T = torch.from_numpy
+
+
+def mapping(g, prefix):
+    return ImageMapping.from_csr_arrays(
+        T(g[prefix + "pointers"]), T(g[prefix + "images"]), T(g[prefix + "pixels"]),
+        T(g[prefix + "features"]), view_pointers=T(g[prefix + "view_pointers"]))
+
+
+def same(m, g, prefix):
+    assert np.array_equal(m.pointers.numpy(), g[prefix + "pointers"]), prefix
+    assert np.array_equal(m.images.numpy(), g[prefix + "images"]), prefix
+    assert np.array_equal(m.values[1].pointers.numpy(), g[prefix + "view_pointers"]), prefix
+    assert np.array_equal(m.pixels.numpy(), g[prefix + "pixels"]), prefix
+    assert np.array_equal(m.features.numpy(), g[prefix + "features"]), prefix
+
+
+def items(g, tag, size):
+    out = []
+    for i in range(3):
+        p = f"{tag}{i}_"
+        n = g[p + "pos"].shape[0]
+        out.append(SameSettingImageData(
+            path=[f"{tag}{i}_{k}" for k in range(n)], pos=T(g[p + "pos"]),
+            extrinsic=torch.eye(4).repeat(n, 1, 1), fx=torch.ones(n), fy=torch.ones(n),
+            mx=torch.zeros(n), my=torch.zeros(n), ref_size=(size, size), proj_upscale=1,
+            downscale=1, x=T(g[p + "x"]), mappings=mapping(g, p)))
+    return out
+
+
+def test_same_setting_image_batch(golden):
+    g = golden("image_batch")
+    big = items(g, "big", 64)
+    b = SameSettingImageBatch.from_data_list(big)
+    assert isinstance(b.mappings, ImageMappingBatch)
+    same(b.mappings, g, "ssb_")
+    assert np.array_equal(b.pos.numpy(), g["ssb_pos"])
+    assert np.array_equal(b.x.numpy(), g["ssb_x"])
+    assert np.array_equal(b.batch_items_sizes, g["ssb_sizes"])
+    assert b.num_views == sum(im.num_views for im in big) and b.num_batch_items == 3
+    back = b.to_data_list()
+    assert [im.num_views for im in back] == [im.num_views for im in big]
+    same(back[1].mappings, g, "ssb_item1_")
+    assert np.array_equal(back[1].pos.numpy(), big[1].pos.numpy())
+    assert torch.equal(back[2].x, big[2].x)
+    # different settings cannot be batched together
+    small = items(g, "small", 32)
+    try:
+        SameSettingImageBatch.from_data_list([big[0], small[0]])
+        raise RuntimeError("expected an AssertionError")
+    except AssertionError:
+        pass
+
+
+def test_select_images_and_views(golden):
+    g = golden("image_batch")
+    m = mapping(g, "big1_")
+    same(m.select_images(T(g["sel_idx"])), g, "sel_")
+    out, img_idx = m.select_views(T(g["view_mask"]))
+    same(out, g, "views_")
+    assert np.array_equal(img_idx.numpy(), g["views_img_idx"])
+    # all views kept: nothing to renumber
+    out, img_idx = m.select_views(torch.ones(m.num_items, dtype=torch.bool))
+    assert img_idx is None and torch.equal(out.pointers, m.pointers)
+    # no image kept: every point becomes empty
+    empty = m.select_images(torch.zeros(0, dtype=torch.int64))
+    assert empty.num_items == 0 and int(empty.pointers.max()) == 0
+    # selecting views of a SameSettingImageData re-indexes its mappings too
+    im = items(g, "big", 64)[1][T(g["sel_idx"])]
+    same(im.mappings, g, "sel_")
+    assert im.num_views == 2
+
+
+def test_image_batch(golden):
+    g = golden("image_batch")
+    big, small = items(g, "big", 64), items(g, "small", 32)
+    ib = ImageBatch.from_data_list([ImageData([a, c]) for a, c in zip(big, small)])
+    assert len(ib) == 2
+    by_size = {int(g[f"ib{k}_ref_size"][0]): k for k in range(2)}
+    n_total = int(g["n_pts"].sum())
+    for ssb in ib:
+        k = by_size[ssb.ref_size[0]]
+        same(ssb.mappings, g, f"ib{k}_")
+        assert np.array_equal(ssb.pos.numpy(), g[f"ib{k}_pos"])
+        assert ssb.mappings.num_groups == n_total
+    back = ib.to_data_list()
+    for i, il in enumerate(back):
+        for k, im in enumerate(il):
+            src = (big, small)[k][i]
+            assert torch.equal(im.mappings.pointers, src.mappings.pointers)
+            assert torch.equal(im.mappings.images, src.mappings.images)
+            assert torch.equal(im.mappings.pixels, src.mappings.pixels)
+            assert torch.equal(im.mappings.features, src.mappings.features)
+            assert torch.equal(im.pos, src.pos)
