@@ -60,3 +60,71 @@ def gather_pooled(features, labels=None, group=None):
         return f, None, counts
     l, _ = gather_rows(labels, group)
     return f, l, counts
+
+
+# --------------------------------------------------------------------------- #
+# One huge scene: views sharded over the ranks                                  #
+# --------------------------------------------------------------------------- #
+# Views are independent for the mapping and for the pixel -> view pool; only
+# the view -> point pool couples the views of a point.  Every rank therefore
+# maps and pools its own block of views against the whole (replicated) cloud
+# and pre-reduces its views per point; one exchange step combines the partial
+# results: all-reduce MAX for the max pool, all-reduce SUM of (sum, count) for
+# the mean pool.
+
+def partition_views(num_views, rank=None, world_size=None):
+    """Contiguous, balanced block of view indices of this rank (a ``range``)."""
+    import torch.distributed as dist
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    base, extra = divmod(int(num_views), world_size)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+def local_view_pools(x_view, view_ptr, segment_csr=None):
+    """Per-point partial pools over this rank's views: (max, sum, count) with
+    max = -inf where the rank holds no view of the point, so that partial
+    maxima of negative features survive the reduction.  ``x_view`` [Vw_r, C]
+    view features in point order, ``view_ptr`` [N + 1] point -> local views."""
+    if segment_csr is None:
+        from .pooling import segment_csr
+    count = (view_ptr[1:] - view_ptr[:-1]).to(x_view.dtype)
+    mx = segment_csr(x_view, view_ptr, reduce='max')
+    sm = segment_csr(x_view, view_ptr, reduce='sum')
+    mx = torch.where(count[:, None] > 0, mx, torch.full_like(mx, float('-inf')))
+    return mx, sm, count
+
+
+def finish_view_pools(mx, sm, count):
+    """(max pool, mean pool) from combined partials: points without any view
+    get 0 in both (the empty-segment value of the pools); mean = sum / count."""
+    seen = count[:, None] > 0
+    mx = torch.where(seen, mx, torch.zeros_like(mx))
+    mean = torch.where(seen, sm / count.clamp(min=1)[:, None], torch.zeros_like(sm))
+    return mx, mean
+
+
+def combine_view_pools(mx, sm, count, group=None):
+    """The exchange step of the view-sharded layout: element-wise MAX of the
+    partial maxima and SUM of the partial sums and counts over the ranks (two
+    all-reduces: the sum and the count travel in one buffer).  Returns
+    (max pool [N, C], mean pool [N, C]) on every rank.  The max pool equals the
+    single-device pool bit for bit; the mean differs from it by float32
+    summation order only."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        mx = mx.contiguous()
+        packed = torch.cat([sm, count[:, None]], dim=1).contiguous()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        sm, count = packed[:, :-1], packed[:, -1]
+    return finish_view_pools(mx, sm, count)
+
+
+def view_sharded_pool(x_view, view_ptr, group=None, segment_csr=None):
+    """View -> point max and mean pools of a scene whose views are sharded over
+    the ranks: local pre-reduction + ``combine_view_pools``."""
+    return combine_view_pools(*local_view_pools(x_view, view_ptr, segment_csr), group=group)

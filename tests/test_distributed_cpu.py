@@ -77,3 +77,73 @@ def test_gather_rows_single_process():
     t = torch.arange(6.).view(3, 2)
     out, counts = D.gather_rows(t)
     assert out is t and counts == [3]
+
+
+# ------------------------------------------------------- view-sharded scene
+def _np_segment_csr(src, ptr, reduce="sum"):
+    import mvf_oracle as orc
+    return torch.from_numpy(orc.segment_csr(src.numpy(), ptr.numpy(), reduce))
+
+
+def _view_scene():
+    """Views of a scene in (point, view) order: per point the ids of the views
+    that see it, with signed features so that empty partial maxima matter."""
+    rng = np.random.default_rng(7)
+    n_pts, n_views, C = 500, 12, 5
+    sees = rng.random((n_pts, n_views)) < 0.3
+    sees[:25] = False                                     # points no view sees
+    feats = rng.normal(size=(n_pts, n_views, C)).astype(np.float32) - 0.5
+    return sees, feats
+
+
+def _local_csr(sees, feats, views):
+    sub = sees[:, list(views)]
+    ptr = np.concatenate([[0], np.cumsum(sub.sum(1))]).astype(np.int64)
+    rows = feats[:, list(views)][sub]
+    return torch.from_numpy(np.ascontiguousarray(rows)), torch.from_numpy(ptr)
+
+
+def _view_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sees, feats = _view_scene()
+        views = D.partition_views(sees.shape[1])
+        x, ptr = _local_csr(sees, feats, views)
+        mx, mean = D.view_sharded_pool(x, ptr, segment_csr=_np_segment_csr)
+        q.put((rank, list(views), mx.numpy(), mean.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partition_views():
+    for world in (1, 2, 3, 8):
+        blocks = [D.partition_views(13, r, world) for r in range(world)]
+        assert [v for b in blocks for v in b] == list(range(13))
+        assert max(len(b) for b in blocks) - min(len(b) for b in blocks) <= 1
+    assert len(D.partition_views(2, 3, 4)) == 0
+
+
+def test_view_sharded_pool_world2_gloo():
+    import mvf_oracle as orc
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_view_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] + res[1][1] == list(range(12))
+    sees, feats = _view_scene()
+    x, ptr = _local_csr(sees, feats, range(12))
+    want_max = orc.segment_csr(x.numpy(), ptr.numpy(), "max")
+    want_mean = orc.segment_csr(x.numpy(), ptr.numpy(), "mean")
+    for r in res:
+        assert np.array_equal(r[2], want_max)             # bit-exact, empties -> 0
+        np.testing.assert_allclose(r[3], want_mean, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(res[0][3], res[1][3])
+    assert (want_max[25:] < 0).any() and not want_max[:25].any()

@@ -224,3 +224,49 @@ def test_c2_non_exact_splat_visibility_full_size():
     _, out = t(data, images)
     assert ref["pixels"].shape[0] > 1_000_000
     check_mapping(out.mappings, ref)
+
+
+def test_view_sharded_scene_equals_single_pass():
+    """The multi-GPU layout of one big scene: two blocks of views mapped and
+    pooled separately against the whole cloud (what two ranks do), partial
+    per-point pools merged as the all-reduces merge them; against one pass over
+    all views.  Max pool bit-exact, mean pool to 1e-5."""
+    from mvfusion import distributed as D
+    from mvfusion.pooling import gather_atomic_pool, segment_csr
+    from mvfusion.transforms import MapImages
+    sc = S.make_scene("c1", seed=31)
+    xyz = sc["xyz"]
+    N, (W, H), V, C_feat = xyz.shape[0], sc["img_size"], sc["pos"].shape[0], 6
+    rng = np.random.default_rng(32)
+    x_all = T(rng.normal(size=(V, C_feat, H, W)).astype(np.float32) - 0.5).to(DEV)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True,
+                  point_order="index", **VIS)
+
+    def run(view_ids):
+        """map + pixel -> view pool of a block of views: (x_view, view_ptr)"""
+        data, images = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=False)
+        sub = images[torch.as_tensor(list(view_ids))]
+        n_sub = sub.num_views
+        _, out = t(data, sub)
+        # views that saw nothing were dropped: recover their ids in the block
+        kept = [k for k in range(n_sub) if any(torch.equal(sub.pos[k], p) for p in out.pos)]
+        x = x_all[torch.as_tensor(list(view_ids))[kept].to(DEV)]
+        m = out.mappings.to(DEV)
+        assert m.pointers.shape[0] == N + 1
+        return gather_atomic_pool(x, m, "max"), m.view_csr_indexing
+
+    xv, ptr = run(range(V))
+    want_max = segment_csr(xv, ptr, reduce="max")
+    want_mean = segment_csr(xv, ptr, reduce="mean")
+    parts = [D.local_view_pools(*run(D.partition_views(V, r, 2))) for r in range(2)]
+    mx = torch.maximum(parts[0][0], parts[1][0])
+    sm, cnt = parts[0][1] + parts[1][1], parts[0][2] + parts[1][2]
+    got_max, got_mean = D.finish_view_pools(mx, sm, cnt)
+    assert torch.equal(cnt.long(), ptr[1:] - ptr[:-1])
+    assert torch.equal(got_max, want_max)
+    assert (want_max < 0).any()
+    torch.testing.assert_close(got_mean, want_mean, rtol=1e-5, atol=1e-6)
+    # single process: the exchange step is the identity
+    one_max, one_mean = D.view_sharded_pool(xv, ptr)
+    assert torch.equal(one_max, want_max)
+    torch.testing.assert_close(one_mean, want_mean, rtol=1e-5, atol=1e-6)
