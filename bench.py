@@ -115,9 +115,36 @@ def cpu_baseline(cfg, C_feat, target_s=12.0):
         if time.perf_counter() - t_all > target_s or len(times) >= 5:
             break
     med = float(np.median(times))
-    return dict(value=N * V / med, unit="points*views/s", cores=1, kind="port",
-                sample=f"{len(times)} full passes of the same workload "
-                       f"({N} pts x {V} views, map + pools), median {med:.3f} s/pass")
+    out = dict(value=N * V / med, unit="points*views/s", cores=1, kind="port",
+               sample=f"{len(times)} full passes of the same workload "
+                      f"({N} pts x {V} views, map + pools), median {med:.3f} s/pass")
+    # the same pass with the views spread over host threads (views are
+    # independent; the merge into the nested CSR and the pools stay serial)
+    workers = min(V, int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count() or 1)
+    if workers > 1:
+        par = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            m = orc.map_images(sc["xyz"], np.arange(N), sc, order=order, ref_size=sc["img_size"],
+                               cylinder=True, workers=workers, **VIS)
+            xv = orc.segment_csr(x_pix, m["view_pointers"], "max")
+            orc.segment_csr(xv, m["pointers"], "max")
+            orc.segment_csr(xv, m["pointers"], "mean")
+            par.append(time.perf_counter() - t0)
+        out["threaded"] = dict(value=N * V / float(np.median(par)), cores=workers,
+                               sample=f"views on {workers} threads, median {np.median(par):.3f} s/pass")
+    out["host"] = dict(cpus=os.cpu_count(), model=cpu_model())
+    return out
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def qkv_flops(N, Vw, F_main, F_map, C, D, G, inner=32):

@@ -744,7 +744,7 @@ def map_images(
         ref_size=None, proj_upscale=1, downscale=1, crop_size=None,
         crop_offsets=None, img_mask=None, cylinder=False, linearity=None,
         planarity=None, scattering=None, normals=None, depth_maps=None,
-        timings=None, **vis_kw):
+        timings=None, workers=1, **vis_kw):
     """MapImages._process, core/data_transform/multimodal/image.py:192-428.
 
     ``cams``: dict with pos [V,3] float64 and, per camera model, extrinsic
@@ -771,8 +771,7 @@ def map_images(
     pdt = pixel_dtype(ref_size)
     T = dict(sample=0.0, visibility=0.0, pixels=0.0, unique=0.0, dense=0.0)
 
-    image_ids, point_ids, features, pixels = [], [], [], []
-    for v in range(V):
+    def one_view(v):
         t0 = time.perf_counter()
         # radius sampling: sklearn KDTree.query_radius keeps points whose
         # float64 distance to the centre is <= r, returned in tree order
@@ -806,10 +805,8 @@ def map_images(
             img_extrinsic=None if cams.get("extrinsic") is None else cams["extrinsic"][v],
             img_mask=img_mask, img_size=proj_size, **kw)
         t2 = time.perf_counter()
-        T["sample"] += t1 - t0
-        T["visibility"] += t2 - t1
         if out["idx"].shape[0] == 0:
-            continue
+            return None, (t1 - t0, t2 - t1, 0.0, 0.0)
         pid = np.asarray(mapping_index, np.int64)[local][out["idx"]]
         px = np.asarray(out["x"]).astype(np.int64)
         py = np.asarray(out["y"]).astype(np.int64)
@@ -824,12 +821,26 @@ def map_images(
         u = lexargunique(pid, px, py)
         px, py, pid, ft = px[u], py[u], pid[u], ft[u]
         t4 = time.perf_counter()
-        T["pixels"] += t3 - t2
-        T["unique"] += t4 - t3
+        return (pid, ft, np.stack([px, py], 1).astype(pdt)), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+
+    # views are independent (the reference loops over them, image.py:238); with
+    # workers > 1 they run on a thread pool (the C loops release the GIL)
+    if workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            results = list(pool.map(one_view, range(V)))
+    else:
+        results = [one_view(v) for v in range(V)]
+    image_ids, point_ids, features, pixels = [], [], [], []
+    for v, (res, dt) in enumerate(results):
+        for k, t in zip(("sample", "visibility", "pixels", "unique"), dt):
+            T[k] += t
+        if res is None:
+            continue
         image_ids.append(v)
-        point_ids.append(pid)
-        features.append(ft)
-        pixels.append(np.stack([px, py], 1).astype(pdt))
+        point_ids.append(res[0])
+        features.append(res[1])
+        pixels.append(res[2])
 
     if len(image_ids) == 0:
         raise ValueError("No mappings were found between the 3D points and any "
