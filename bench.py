@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=3,
+                    help="streams that consecutive steps alternate between (1 = no overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -299,18 +301,33 @@ def main():
                                               inner="max", outer=("max", "mean"))
         return x_max, x_mean, P
 
+    # Consecutive samples are independent: steps alternate between two streams
+    # (each with its own plan: outputs, workspace, centre map), so that the
+    # latency-bound kernels of one step overlap with the other step's.  On each
+    # stream the mapping pass of the next step is enqueued before the sizes of
+    # the current one are waited for, so the device does not idle on the host
+    # round trip.
+    n_lanes = max(1, args.lanes)
+    plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
+    streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
+
     def run_steps(k):
-        """k full steps (mapping pass, size read-back, three pools each).  The
-        mapping pass of step j + 1 is enqueued before the sizes of step j are
-        waited for, so the device does not idle on the host round trip."""
+        """k full steps (mapping pass, size read-back, three pools each)."""
         out = None
-        if k <= 0:
-            return out
-        pending = plan.run_async()
+        pending = [None] * n_lanes
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(device))
+        for j in range(min(n_lanes, k)):
+            with torch.cuda.stream(streams[j]):
+                pending[j] = plans[j].run_async()
         for j in range(k):
-            nxt = plan.run_async() if j + 1 < k else None
-            out = pools(pending.result())
-            pending = nxt
+            ln = j % n_lanes
+            with torch.cuda.stream(streams[ln]):
+                nxt = plans[ln].run_async() if j + n_lanes < k else None
+                out = pools(pending[ln].result())
+                pending[ln] = nxt
+        for s in streams:
+            torch.cuda.current_stream(device).wait_stream(s)
         return out
 
     def barrier():
@@ -398,6 +415,7 @@ def main():
                        "name": cfg, "points_per_gpu": N, "views": V, "image": [W, H],
                        "mappings_per_sample": plan.last_counts["mappings"],
                        "splat_tile_pairs": plan.last_counts["pairs"],
+                       "streams_per_gpu": n_lanes,
                        "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
             "roofline": roofline,
         }

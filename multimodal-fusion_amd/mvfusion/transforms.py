@@ -99,12 +99,15 @@ def pack_views(images, camera):
 
 class _CentreWorkspace:
     """Persistent per-device uint64 map shared by successive fused calls: it is
-    zeroed once, every call tags its entries with a fresh epoch."""
+    zeroed once, every call tags its entries with a fresh epoch.  Calls that
+    may run concurrently (plans driven on different streams) must not share a
+    map -- a later epoch would overwrite the stamps of a pass still in flight --
+    so every ``lane`` has its own."""
     _cache = {}
 
     @classmethod
-    def get(cls, device, n_elems):
-        key = (device.index, )
+    def get(cls, device, n_elems, lane=0):
+        key = (device.index, lane)
         ws = cls._cache.get(key)
         if ws is None or ws[0].numel() < n_elems or ws[1] >= 2 ** 32 - 2:
             ws = [torch.zeros(n_elems, dtype=torch.int64, device=device), 0]
@@ -128,7 +131,8 @@ class FusedMapPlan:
     SLOTS = 2
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
-                 downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None):
+                 downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
+                 lane=0):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
         self.views, self.mask, self.params = views, mask, params
         self.cylinder, self.upscale, self.downscale, self.crop_size = \
@@ -141,6 +145,15 @@ class FusedMapPlan:
         self._ws = None
         self._turn = 0
         self.last_counts = None
+        self.lane = lane
+
+    def twin(self, lane):
+        """A second plan over the same staged sample with its own outputs,
+        workspace and centre map, to be driven on another stream."""
+        return FusedMapPlan(
+            self.pos, self.ids, self.inv, self.attrs, self.views, self.mask, self.params,
+            self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
+            self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane)
 
     def _slot(self, k):
         """Output buffers of slot k: (out_cap, counters, host counters, event,
@@ -175,7 +188,7 @@ class FusedMapPlan:
         lib = L.load()
         P = self.params
         Hc = P.H - P.crop_top - P.crop_bottom
-        centre_ws, epoch = _CentreWorkspace.get(self.device, self.V * P.W * Hc)
+        centre_ws, epoch = _CentreWorkspace.get(self.device, self.V * P.W * Hc, self.lane)
         sl = self._slot(slot)
         _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = sl
         ws = self._workspace()

@@ -266,6 +266,46 @@ def test_fused_plan_async_matches_sync():
     assert plan.out_cap > 16 and plan.pair_cap > 16
 
 
+def test_fused_plans_on_concurrent_streams():
+    """Three plans over two different samples driven on three streams at once
+    (what bench.py does with consecutive steps): every pass returns exactly
+    what a lone synchronous pass returns.  The plans own separate workspaces
+    and centre maps (lanes); sharing a centre map between passes in flight
+    would let the later epoch erase the earlier pass's stamps."""
+    from mvfusion import visibility as visibility_module
+    from mvfusion.transforms import MapImages
+    dev0 = torch.device("cuda", 0)
+    plans, wants = [], []
+    for seed in (6, 7):
+        sc = S.make_scene("c1", seed=seed)
+        N = sc["xyz"].shape[0]
+        data, images = make_inputs(sc["xyz"], np.arange(N), sc, sc["img_size"], attrs=False)
+        t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+        model = visibility_module.SplattingVisibility(img_size=images.proj_size, exact=True, **VIS)
+        plan = t.prepare_fused(data, images, model, dev0)
+        plans.append(plan)
+        wants.append([x.clone() for x in plan.run()])
+    plans.append(plans[0].twin(lane=2))
+    wants.append(wants[0])
+    plans[1].lane = 1
+    assert len({p.lane for p in plans}) == 3
+    streams = [torch.cuda.Stream(dev0) for _ in plans]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        pending = []
+        for plan, s in zip(plans, streams):
+            with torch.cuda.stream(s):
+                pending.append((plan.run_async(), plan.run_async()))
+        for (p0, p1), s, want in zip(pending, streams, wants):
+            with torch.cuda.stream(s):
+                for p in (p0, p1):
+                    got = [x.clone() for x in p.result()]
+                    s.synchronize()
+                    for g_, w_ in zip(got, want):
+                        assert torch.equal(g_, w_)
+    torch.cuda.synchronize()
+
+
 def test_map_images_no_mapping_raises():
     from mvfusion.transforms import MapImages
     sc = S.make_scene("c1", seed=3, n_points=2000, n_views=2)
