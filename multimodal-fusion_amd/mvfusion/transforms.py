@@ -273,6 +273,8 @@ class MapImages(ImageTransform):
         self.use_cuda = use_cuda
         self.point_order = kwargs.pop('point_order', 'kdtree')
         assert self.point_order in ('kdtree', 'index')
+        # streams a list of samples is spread over (fused path only)
+        self.lanes = int(kwargs.pop('lanes', 3))
         self.kwargs = kwargs
         self._pair_cap = None
         self._out_cap = None
@@ -295,21 +297,88 @@ class MapImages(ImageTransform):
                 and ints and images.pixel_dtype == torch.int16
                 and images.is_pinhole and images.has_extrinsic)
 
-    def _process(self, data, images):
+    def _settle(self, data, images):
+        """Checks and image settings of image.py:192-215; returns the
+        visibility model of these images."""
         assert hasattr(data, self.key)
         assert images.num_views >= 1, "At least one image must be provided."
-        in_device = images.device
-        device = L.require_device(data.pos)
-
         if self.ref_size is not None:
             images.ref_size = self.ref_size
         if self.proj_upscale is not None:
             images.proj_upscale = self.proj_upscale
         if images.mask is not None:
             assert tuple(images.mask.shape) == tuple(images.proj_size)
-
         visi_cls = getattr(visibility_module, self.method)
-        visi_model = visi_cls(img_size=images.proj_size, **self.kwargs)
+        return visi_cls(img_size=images.proj_size, **self.kwargs)
+
+    def __call__(self, data, images):
+        if isinstance(data, list) and len(data) > 1 and self.lanes > 1 \
+                and isinstance(images, list) and len(data) == len(images) \
+                and not any(isinstance(im, ImageData) for im in images):
+            out = self._process_list_fused(data, images)
+            if out is not None:
+                return out
+        return super(MapImages, self).__call__(data, images)
+
+    def _process_list_fused(self, data_list, images_list):
+        """A list of independent samples on the fused path: the passes are
+        spread over ``lanes`` streams so that the latency-bound kernels of one
+        sample overlap with those of the others; results are those of the
+        one-by-one loop.  Returns None when a sample cannot take the fused
+        path (the caller then loops)."""
+        device = L.require_device(data_list[0].pos)
+        staged = []
+        for data, images in zip(data_list, images_list):
+            visi_model = self._settle(data, images)
+            if not self._fusable(images, visi_model):
+                return None
+            plan = self.prepare_fused(data, images, visi_model, device)
+            if plan is None:
+                return None
+            staged.append((data, images, visi_model, plan))
+        n_lanes = min(self.lanes, len(staged))
+        current = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
+        pending = []
+        for k, (_, _, _, plan) in enumerate(staged):
+            plan.lane = k % n_lanes          # one centre map per stream
+            s = streams[plan.lane]
+            plan._slot(0)                    # buffers belong to the caller's stream
+            plan._workspace()
+            s.wait_stream(current)           # inputs were staged on the caller's stream
+            with torch.cuda.stream(s):
+                pending.append(plan.run_async())
+        results = []
+        for (_, _, _, plan), p in zip(staged, pending):
+            with torch.cuda.stream(streams[plan.lane]):
+                res = p.result()
+            for t in res:                    # consumed on the caller's stream from here on
+                t.record_stream(current)
+            results.append(res)
+            self._pair_cap = max(self._pair_cap or 0, plan.pair_cap)
+            self._out_cap = max(self._out_cap or 0, plan.out_cap)
+        for s in streams:
+            current.wait_stream(s)
+        data_out, images_out = [], []
+        for (data, images, visi_model, _), res in zip(staged, results):
+            pointers, img_ids, pixels, feats, view_seen = res
+            if img_ids.shape[0] == 0:
+                raise ValueError(_NO_MAPPING_MSG)
+            in_device = images.device
+            mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)
+            seen = torch.where(view_seen > 0)[0]
+            if seen.shape[0] != images.num_views:
+                images = images[seen.to(in_device)]
+            images.mappings = mappings.to(in_device)
+            images.visibility = visi_model
+            data_out.append(data)
+            images_out.append(images)
+        return data_out, images_out
+
+    def _process(self, data, images):
+        in_device = images.device
+        device = L.require_device(data.pos)
+        visi_model = self._settle(data, images)
 
         mappings = seen = None
         if self._fusable(images, visi_model):

@@ -270,3 +270,36 @@ def test_view_sharded_scene_equals_single_pass():
     one_max, one_mean = D.view_sharded_pool(xv, ptr)
     assert torch.equal(one_max, want_max)
     torch.testing.assert_close(one_mean, want_mean, rtol=1e-5, atol=1e-6)
+
+
+def test_map_images_list_of_samples_multi_stream():
+    """MapImages on a list of cylinders (the per-GPU batch of C4) spreads the
+    fused passes over three streams; results equal the one-by-one calls."""
+    from mvfusion.transforms import MapImages, kdtree_order
+    scenes = [S.make_scene("c1", seed=40 + k, n_points=60000) for k in range(5)]
+
+    def inputs():
+        pairs = [make_inputs(sc["xyz"], np.arange(sc["xyz"].shape[0]), sc, sc["img_size"],
+                             attrs=(k % 2 == 0)) for k, sc in enumerate(scenes)]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, **VIS)
+    data, images = inputs()
+    _, out_list = t(data, images)
+    one = MapImages(method="SplattingVisibility", cylinder=True, exact=True, lanes=1, **VIS)
+    data, images = inputs()
+    assert len(out_list) == len(scenes)
+    for k, (da, im) in enumerate(zip(data, images)):
+        _, want = one(da, im)
+        got = out_list[k]
+        assert got.num_views == want.num_views
+        for a, b in ((got.mappings.pointers, want.mappings.pointers),
+                     (got.mappings.images, want.mappings.images),
+                     (got.mappings.pixels, want.mappings.pixels),
+                     (got.mappings.features, want.mappings.features)):
+            assert torch.equal(a, b), k
+    # and against the oracle for one of them
+    sc = scenes[1]
+    ref = orc.map_images(sc["xyz"], np.arange(sc["xyz"].shape[0]), sc,
+                         order=kdtree_order(T(sc["xyz"]), True).numpy(), ref_size=sc["img_size"], cylinder=True, exact=True, **VIS)
+    check_mapping(out_list[1].mappings, ref, features_atol=1e-6)
