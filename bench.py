@@ -329,6 +329,11 @@ def main():
     n_lanes = max(1, args.lanes)
     plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
     streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
+    # set-up: every lane allocates its outputs, workspace and centre map once
+    for p_, s_ in zip(plans, streams):
+        with torch.cuda.stream(s_):
+            p_.run()
+    torch.cuda.synchronize()
 
     def run_steps(k):
         """k full steps (mapping pass, size read-back, three pools each)."""
