@@ -216,6 +216,17 @@ int mvf_segment_csr(
     const float *src, int64_t rows, int32_t C, const int64_t *ptr, int64_t nseg,
     int32_t reduce, float *out, void *stream);
 
+/* Gradient of segment_csr with respect to src, as torch_scatter's autograd
+ * function computes it (torch_scatter is the reference's dependency for
+ * pooling.py:63): sum -> the segment's gradient on every row, mean -> divided
+ * by the row count, max / min -> on the first row holding the reduced value
+ * (src and out = the forward's input and output, may be NULL for sum / mean).
+ * Rows outside every segment are left untouched: pass a zeroed grad_src when
+ * ptr[0] > 0 or ptr[nseg] < rows. */
+int mvf_segment_csr_backward(
+    const float *grad_out, const float *src, const float *out, int64_t rows, int32_t C,
+    const int64_t *ptr, int64_t nseg, int32_t reduce, float *grad_src, void *stream);
+
 /* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
 int mvf_gather_csr(
     const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,

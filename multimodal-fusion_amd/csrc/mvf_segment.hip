@@ -364,6 +364,37 @@ __global__ __launch_bounds__(256) void sparse_interp_kernel(
     }
 }
 
+// Backward of segment_csr (the gradient torch_scatter attaches to it): one
+// thread per (segment, channel).  sum: every row of the segment receives the
+// segment's gradient; mean: divided by the row count; max / min: the FIRST row
+// that holds the reduced value receives it (the forward keeps the first of
+// equal values), the other rows zero.
+template <int MODE>
+__global__ __launch_bounds__(256) void segment_csr_backward_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ src, const float *__restrict__ out,
+    int C, const i64 *__restrict__ ptr, i64 nseg, float *__restrict__ grad_src)
+{
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nseg * C) return;
+    const i64 sg = e / C;
+    const int c = (int)(e - sg * C);
+    const i64 a = ptr[sg], b = ptr[sg + 1];
+    if (b <= a) return;
+    float g = grad_out[e];
+    if (MODE == MVF_REDUCE_SUM || MODE == MVF_REDUCE_MEAN) {
+        if (MODE == MVF_REDUCE_MEAN) g = __fdiv_rn(g, (float)(b - a));
+        for (i64 r = a; r < b; ++r) grad_src[(size_t)r * C + c] = g;
+    } else {
+        const float best = out[e];
+        bool given = false;
+        for (i64 r = a; r < b; ++r) {
+            const bool hit = !given && src[(size_t)r * C + c] == best;
+            grad_src[(size_t)r * C + c] = hit ? g : 0.f;
+            given = given || hit;
+        }
+    }
+}
+
 static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr_log)
 {
     vec = (C % 4 == 0 && ((uintptr_t)p0 % 16 == 0) && ((uintptr_t)p1 % 16 == 0)) ? 4 : 1;
@@ -401,6 +432,31 @@ extern "C" int mvf_segment_csr(
     if (vec == 4) { MVF_SEG_MODE(4) } else { MVF_SEG_MODE(1) }
 #undef MVF_SEG_MODE
 #undef MVF_SEG
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_segment_csr_backward(
+    const float *grad_out, const float *src, const float *out, int64_t rows, int32_t C,
+    const int64_t *ptr, int64_t nseg, int32_t reduce, float *grad_src, void *stream)
+{
+    MVF_REQUIRE(C >= 1 && nseg >= 0 && rows >= 0, "segment_csr_backward: bad shape");
+    MVF_REQUIRE(reduce >= 0 && reduce <= 3, "segment_csr_backward: unknown reduce %d", reduce);
+    if (nseg == 0 || rows == 0) return MVF_OK;
+    MVF_REQUIRE(grad_out && ptr && grad_src, "segment_csr_backward: null pointer");
+    const bool sel = reduce == MVF_REDUCE_MIN || reduce == MVF_REDUCE_MAX;
+    MVF_REQUIRE(!sel || (src && out), "segment_csr_backward: max / min need src and out");
+    dim3 grid(cdiv(nseg * C, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define MVF_SB(M_) hipLaunchKernelGGL((segment_csr_backward_kernel<M_>), grid, block, 0, st, grad_out, src, \
+                                      out, C, (const i64 *)ptr, (i64)nseg, grad_src)
+    switch (reduce) {
+    case MVF_REDUCE_SUM: MVF_SB(MVF_REDUCE_SUM); break;
+    case MVF_REDUCE_MEAN: MVF_SB(MVF_REDUCE_MEAN); break;
+    case MVF_REDUCE_MIN: MVF_SB(MVF_REDUCE_MIN); break;
+    default: MVF_SB(MVF_REDUCE_MAX); break;
+    }
+#undef MVF_SB
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

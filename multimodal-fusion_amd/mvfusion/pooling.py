@@ -34,9 +34,47 @@ def _prep(src, csr_idx):
     return src.detach().contiguous(), ptr
 
 
+class _SegmentCSR(torch.autograd.Function):
+    """segment_csr with the gradient torch_scatter defines for it: sum / mean
+    spread the segment's gradient over its rows, max / min route it to the first
+    row that holds the reduced value."""
+
+    @staticmethod
+    def forward(ctx, src, indptr, reduce):
+        res = segment_csr(src.detach(), indptr, reduce=reduce)
+        ctx.reduce = reduce
+        ctx.shape = src.shape
+        keep = reduce in ('max', 'min')
+        ctx.save_for_backward(indptr, *((src.detach(), res) if keep else ()))
+        return res
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        saved = ctx.saved_tensors
+        ptr = saved[0].to(device=grad_out.device, dtype=torch.int64).contiguous()
+        src, res = (saved[1].contiguous(), saved[2]) if len(saved) == 3 else (None, None)
+        g = grad_out.detach().float().contiguous()
+        grad_src = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        nseg = ptr.shape[0] - 1
+        rows = ctx.shape[0]
+        C_ = 1
+        for d in ctx.shape[1:]:
+            C_ *= int(d)
+        if nseg > 0 and rows > 0 and C_ > 0:
+            lib = L.load()
+            with torch.cuda.device(g.device):
+                L.check(lib.mvf_segment_csr_backward(
+                    L.ptr(g), L.ptr(src), L.ptr(res), rows, C_, L.ptr(ptr), nseg,
+                    L.REDUCE[ctx.reduce], L.ptr(grad_src), L.stream_ptr(g.device)))
+        return grad_src, None, None
+
+
 def segment_csr(src, indptr, out=None, reduce="sum"):
     """Drop-in for ``torch_scatter.segment_csr`` on dim 0 of a 1D/2D float32
-    tensor with 1D pointers: empty segment -> 0, mean = sum / count."""
+    tensor with 1D pointers: empty segment -> 0, mean = sum / count.
+    Differentiable with respect to ``src`` (when ``out`` is not given)."""
+    if out is None and torch.is_grad_enabled() and src.requires_grad:
+        return _SegmentCSR.apply(src, indptr, reduce)
     src_c, ptr = _prep(src, indptr)
     lib = L.load()
     nseg = ptr.shape[0] - 1

@@ -242,3 +242,48 @@ def test_gather_features_and_interpolation_vs_oracle_large():
             T(ptr).cuda(), T(images + B).cuda(), T(pixels).cuda(), None,
             view_pointers=T(vptr).cuda())
         P.gather_features(T(x).cuda(), bad)
+
+
+# ------------------------------------------------------------------ backward
+@pytest.mark.parametrize("mode", ["sum", "mean", "max", "min"])
+def test_bimodal_pool_backward(mode):
+    """Gradient of BimodalCSRPool / segment_csr with respect to the pooled
+    features against torch.segment_reduce's autograd on the CPU (empty,
+    singleton and long segments; no ties in the random data), plus the
+    first-occurrence rule for equal maxima."""
+    from mvfusion.pooling import BimodalCSRPool, segment_csr
+    rng = np.random.default_rng(51)
+    sizes = rng.poisson(4, 3000)
+    sizes[rng.random(3000) < 0.15] = 0
+    sizes[7] = 900
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    rows, C = int(ptr[-1]), 13
+    x = rng.normal(size=(rows, C)).astype(np.float32)
+    w = rng.normal(size=(len(sizes), C)).astype(np.float32)
+
+    xg = T(x).requires_grad_(True)
+    pool = BimodalCSRPool(mode=mode)
+    out = pool(None, xg, None, T(ptr))
+    (out * T(w)).sum().backward()
+
+    xc = torch.from_numpy(x).requires_grad_(True)
+    ref = torch.segment_reduce(xc, mode, offsets=torch.from_numpy(ptr), axis=0, initial=0.0) \
+        if mode in ("sum", "mean") else \
+        torch.segment_reduce(xc, mode, offsets=torch.from_numpy(ptr), axis=0)
+    ref = torch.where(torch.from_numpy(sizes > 0)[:, None], ref, torch.zeros_like(ref))
+    (ref * torch.from_numpy(w)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xc.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+    if mode in ("max", "min"):
+        # equal values: the first row of the segment takes the whole gradient
+        t = T(np.array([[1.0], [3.0], [3.0], [2.0], [2.0]], np.float32)).requires_grad_(True)
+        sign = 1.0 if mode == "max" else -1.0
+        o = segment_csr(t * sign, T(np.array([0, 3, 5], np.int64)), reduce=mode)
+        o.sum().backward()
+        want = [0, 1, 0, 1, 0] if mode == "max" else [0, 1, 0, 1, 0]
+        assert (t.grad.view(-1).cpu() * sign).tolist() == [float(v) for v in want]
+    # no graph is recorded when gradients are off or not needed
+    with torch.no_grad():
+        assert not segment_csr(xg, T(ptr), reduce=mode).requires_grad
+    assert not segment_csr(T(x), T(ptr), reduce=mode).requires_grad
