@@ -227,6 +227,16 @@ int mvf_segment_csr_backward(
     const float *grad_out, const float *src, const float *out, int64_t rows, int32_t C,
     const int64_t *ptr, int64_t nseg, int32_t reduce, float *grad_src, void *stream);
 
+/* Gradient of segment_softmax_csr (pooling.py:770-822) with respect to its
+ * input, given the forward output y [rows][G]:
+ * grad_src = y * (grad_out - sum over the segment of grad_out * y) / s, with
+ * s = sqrt(rows of the segment) when scaling.  Terms of the order of the
+ * reference's eps = 1e-12 are dropped.  Rows outside every segment are left
+ * untouched. */
+int mvf_segment_softmax_csr_backward(
+    const float *grad_out, const float *y, int32_t G, const int64_t *ptr, int64_t nseg,
+    int32_t scaling, float *grad_src, void *stream);
+
 /* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
 int mvf_gather_csr(
     const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,

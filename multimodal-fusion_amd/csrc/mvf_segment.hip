@@ -395,6 +395,30 @@ __global__ __launch_bounds__(256) void segment_csr_backward_kernel(
     }
 }
 
+// Backward of segment_softmax_csr: with y = softmax of x / s inside the segment
+// (s = sqrt(rows) when scaling), grad_x = y * (g - sum_rows(g * y)) / s.  The
+// reference's eps in the denominator and its max-centring change the gradient
+// by O(eps) and are not differentiated through.  One thread per (segment,
+// group), rows folded in order.
+__global__ __launch_bounds__(256) void segment_softmax_backward_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ y, int G,
+    const i64 *__restrict__ ptr, i64 nseg, int scaling, float *__restrict__ grad_src)
+{
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nseg * G) return;
+    const i64 sg = e / G;
+    const int g = (int)(e - sg * G);
+    const i64 a = ptr[sg], b = ptr[sg + 1];
+    if (b <= a) return;
+    float dot = 0.f;
+    for (i64 r = a; r < b; ++r) dot = __fmaf_rn(grad_out[(size_t)r * G + g], y[(size_t)r * G + g], dot);
+    const float inv = scaling ? __fdiv_rn(1.0f, sqrtf((float)(b - a))) : 1.0f;
+    for (i64 r = a; r < b; ++r) {
+        const size_t k = (size_t)r * G + g;
+        grad_src[k] = __fmul_rn(__fmul_rn(y[k], __fsub_rn(grad_out[k], dot)), inv);
+    }
+}
+
 static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr_log)
 {
     vec = (C % 4 == 0 && ((uintptr_t)p0 % 16 == 0) && ((uintptr_t)p1 % 16 == 0)) ? 4 : 1;
@@ -491,6 +515,19 @@ extern "C" int mvf_segment_softmax_csr(
     const i64 threads = nseg * G;
     hipLaunchKernelGGL(segment_softmax_kernel, dim3(cdiv(threads, 256)), dim3(256), 0,
                        (hipStream_t)stream, src, G, (const i64 *)ptr, (i64)nseg, eps, scaling, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_segment_softmax_csr_backward(
+    const float *grad_out, const float *y, int32_t G, const int64_t *ptr, int64_t nseg,
+    int32_t scaling, float *grad_src, void *stream)
+{
+    MVF_REQUIRE(G >= 1 && nseg >= 0, "segment_softmax_csr_backward: bad shape");
+    if (nseg == 0) return MVF_OK;
+    MVF_REQUIRE(grad_out && y && ptr && grad_src, "segment_softmax_csr_backward: null pointer");
+    hipLaunchKernelGGL(segment_softmax_backward_kernel, dim3(cdiv(nseg * G, 256)), dim3(256), 0,
+                       (hipStream_t)stream, grad_out, y, G, (const i64 *)ptr, (i64)nseg, scaling, grad_src);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

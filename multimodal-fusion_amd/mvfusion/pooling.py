@@ -119,9 +119,51 @@ def segment_csr_two_level(src, inner_ptr, outer_ptr, inner="max", outer=("max",)
     return tuple(outs)
 
 
+class _GatherCSR(torch.autograd.Function):
+    """gather_csr; its gradient is the segment sum of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, src, csr_idx):
+        ctx.save_for_backward(csr_idx)
+        return gather_csr(src.detach(), csr_idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (csr_idx,) = ctx.saved_tensors
+        return segment_csr(grad_out.detach().float().contiguous(), csr_idx, reduce='sum'), None
+
+
+class _SegmentSoftmaxCSR(torch.autograd.Function):
+    """segment_softmax_csr with y * (g - sum(g * y)) / scale as gradient."""
+
+    @staticmethod
+    def forward(ctx, src, csr_idx, eps, scaling):
+        y = segment_softmax_csr(src.detach(), csr_idx, eps=eps, scaling=scaling)
+        ctx.scaling = bool(scaling)
+        ctx.save_for_backward(csr_idx, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        csr_idx, y = ctx.saved_tensors
+        g = grad_out.detach().float().contiguous()
+        ptr = csr_idx.to(device=g.device, dtype=torch.int64).contiguous()
+        grad = torch.zeros_like(y)
+        if y.numel() > 0:
+            lib = L.load()
+            G = 1 if y.dim() == 1 else y.shape[1]
+            with torch.cuda.device(g.device):
+                L.check(lib.mvf_segment_softmax_csr_backward(
+                    L.ptr(g), L.ptr(y), G, L.ptr(ptr), ptr.shape[0] - 1, int(ctx.scaling),
+                    L.ptr(grad), L.stream_ptr(g.device)))
+        return grad, None, None, None
+
+
 def gather_csr(src, csr_idx):
     """Gather index-level src values into element-level values based on CSR
-    indices (pooling.py:825-853)."""
+    indices (pooling.py:825-853).  Differentiable with respect to ``src``."""
+    if torch.is_grad_enabled() and src.requires_grad:
+        return _GatherCSR.apply(src, csr_idx)
     if not torch.is_floating_point(src):
         raise ValueError(
             '`gather_csr` can only be computed over tensors with '
@@ -150,7 +192,10 @@ def segment_gather_csr(src, csr_idx, reduce='sum'):
 
 
 def segment_softmax_csr(src, csr_idx, eps=1e-12, scaling=False):
-    """Softmax inside CSR segments (pooling.py:770-822)."""
+    """Softmax inside CSR segments (pooling.py:770-822).  Differentiable with
+    respect to ``src``."""
+    if torch.is_grad_enabled() and src.requires_grad:
+        return _SegmentSoftmaxCSR.apply(src, csr_idx, eps, scaling)
     if not torch.is_floating_point(src):
         raise ValueError(
             '`segment_csr_softmax` can only be computed over tensors with '
@@ -430,6 +475,9 @@ class MinMaxDiffSetFeat(nn.Module, ABC):
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
+        if self.training:
+            from . import training
+            return training.min_max_diff_set_feat(self, x, ptr)
         return self.embed(x, ptr, None)
 
     def extra_repr(self) -> str:
@@ -484,6 +532,9 @@ class DeepSetFeat(nn.Module, ABC):
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
+        if self.training:
+            from . import training
+            return training.deep_set_feat(self, x, ptr)
         return self.embed(x, ptr, None)
 
     def extra_repr(self) -> str:
@@ -504,6 +555,9 @@ class MLPSetFeat(nn.Module, ABC):
         return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x, dot=dot)
 
     def forward(self, x, csr_idx):
+        if self.training:
+            from . import training
+            return training.mlp(self.mlp, x)
         return self.embed(x, None, None)
 
 
@@ -556,12 +610,26 @@ class _AttentivePool(nn.Module, ABC):
         return cache[key]
 
     def _check_mode(self):
-        if self.training:
-            raise RuntimeError(
-                f"{type(self).__name__}: only inference is implemented (BatchNorm with "
-                f"running statistics, no backward): call .eval() first")
-        if self.G is not None and self.G._activation != 'tanh+':
+        if self.G is not None and self.G._activation != 'tanh+' and not self.training:
             raise NotImplementedError("the attention kernel implements the 'tanh+' gate only")
+
+    def _forward_train(self, composed, x_main, x_mod, x_map, csr_idx):
+        """Training mode: differentiable composition (training.py) instead of
+        the fused inference kernels."""
+        ptr = _device_ptr(x_mod, csr_idx)
+        x_pool, parts = composed(self, x_main, x_mod, x_map, ptr)
+        if self.save_last:
+            self._last_x_map = parts['x_map']
+            self._last_x_mod = parts['x_mod']
+            self._last_idx = _last_idx(csr_idx, x_mod.device)
+            self._last_view_num = csr_idx[1:] - csr_idx[:-1]
+            if 'K' in parts:
+                self._last_K, self._last_Q = parts['K'], parts['Q']
+            self._last_C = parts['C']
+            self._last_A = parts['A']
+            if self.G:
+                self._last_G = parts['G']
+        return x_pool
 
 
 class GroupBimodalCSRPool(_AttentivePool):
@@ -609,6 +677,9 @@ class GroupBimodalCSRPool(_AttentivePool):
         :return: x_pool
         """
         self._check_mode()
+        if self.training:
+            from . import training
+            return self._forward_train(training.group_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)
         row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
         score = [_dense.linear_layer(self.E_score)]
@@ -705,6 +776,9 @@ class QKVBimodalCSRPool(_AttentivePool):
         :return: x_pool
         """
         self._check_mode()
+        if self.training:
+            from . import training
+            return self._forward_train(training.qkv_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)
         row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
         k_lin, q_lin = [_dense.linear_layer(self.K)], [_dense.linear_layer(self.Q)]

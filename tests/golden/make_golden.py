@@ -618,6 +618,60 @@ def gen_attention_pools():
          **{k: np.asarray(v) for k, v in kw.items()}, **sd)
 
 
+def gen_training():
+    """One training step of the attentive pools in the reference (``.train()``:
+    BatchNorm with batch statistics): output, gradients of sum(out * w) with
+    respect to the inputs and to every parameter, running statistics after the
+    step.  The torch_scatter stand-in of the loader is plain differentiable
+    torch code."""
+    import contextlib
+    import io
+    pooling = ref["pooling"]
+    rng = np.random.default_rng(12)
+    N, F_main, F_map, C = 300, 32, 8, 64
+    ptr = random_ptr(rng, N, 4)
+    Vw = int(ptr[-1])
+    x_main = rng.random((N, F_main)).astype(np.float32)
+    x_mod = rng.random((Vw, C)).astype(np.float32)
+    x_map = rng.random((Vw, F_map)).astype(np.float32)
+    w = rng.normal(size=(N, C)).astype(np.float32)
+    cases = {
+        "train_qkv": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, num_groups=1, nc_qk=16, gating=True, dim_scaling=True,
+            group_scaling=False, use_num=True, map_encoder="DeepSetFeat")),
+        "train_qkv_groups4_modk": ("QKVBimodalCSRPool", dict(
+            in_main=F_main, num_groups=4, nc_qk=8, gating=True, dim_scaling=True,
+            group_scaling=True, use_mod_k=True, map_encoder="MinMaxDiffSetFeat", use_num=True)),
+        "train_group": ("GroupBimodalCSRPool", dict(
+            num_groups=4, gating=True, group_scaling=True, use_num=True,
+            map_encoder="DeepSetFeat")),
+    }
+    for name, (cls, kw) in cases.items():
+        torch.manual_seed(sum(map(ord, name)))
+        gen = torch.Generator().manual_seed(len(name))
+        mod = getattr(pooling, cls)(in_map=F_map, in_mod=C, out_mod=C, **kw)
+        with torch.no_grad():
+            randomise_bn(mod, gen)
+            mod.G.weight.copy_(torch.rand(1, kw["num_groups"], generator=gen) + 0.5)
+            mod.G.bias.copy_(torch.randn(1, kw["num_groups"], generator=gen) * 0.1)
+        sd0 = {"sd." + k: v.clone().numpy() for k, v in mod.state_dict().items()}
+        mod.train()
+        xs = [T(a.copy()).requires_grad_(True) for a in (x_main, x_mod, x_map)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = mod(xs[0] if cls.startswith("QKV") else None, xs[1], xs[2], T(ptr))
+        (out * T(w)).sum().backward()
+        arrs = dict(x_main=x_main, x_mod=x_mod, x_map=x_map, ptr=ptr, w=w, x_pool=out.detach().numpy(),
+                    g_x_mod=xs[1].grad.numpy(), g_x_map=xs[2].grad.numpy(), cls=cls)
+        if cls.startswith("QKV"):
+            arrs["g_x_main"] = xs[0].grad.numpy()
+        for k, p_ in mod.named_parameters():
+            arrs["grad." + k] = p_.grad.numpy()
+        for k, v in mod.state_dict().items():
+            if "running_" in k:
+                arrs["after." + k] = v.numpy()
+        save(name, **arrs, **{"kw." + k: np.asarray(v) for k, v in kw.items()}, **sd0)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -671,6 +725,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training"]
     for w in which:
         globals()["gen_" + w]()
