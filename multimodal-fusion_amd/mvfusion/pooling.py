@@ -8,8 +8,10 @@ pooling.py): BimodalCSRPool :14-71, segment_softmax_csr :770-822, gather_csr
 :825-853, segment_gather_csr :856-868, expand_group_feat :760-767,
 group_sizes :749-757, HeuristicBimodalCSRPool :74-156, GroupBimodalCSRPool :159-319,
 QKVBimodalCSRPool :322-551, MinMaxDiffSetFeat :554-601, DeepSetFeat :604-685,
-MLPSetFeat :688-699, Gating :702-727.  Forward (inference) only: no autograd
-graph is recorded through the HIP kernels.
+MLPSetFeat :688-699, Gating :702-727.  ``segment_csr``, ``gather_csr`` and
+``segment_softmax_csr`` are differentiable; the attentive pools use fused
+inference kernels in ``.eval()`` and a differentiable composition
+(``training.py``) in ``.train()``.
 """
 import math
 import sys
