@@ -366,6 +366,26 @@ int mvf_segment_pick(
     const float *x_mod, int32_t C, const float *feat, int32_t ldf, const int64_t *ptr,
     int64_t nseg, int32_t pick_max, float *out, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * NeighborhoodBasedMappingFeatures
+ * (core/data_transform/multimodal/image.py:431-612).
+ * mvf_knn: the k <= 64 nearest neighbours of every point among the n points
+ * (the point itself included, first), neighbors [n][k] ascending in distance;
+ * exact: float64 squared distances of the float32 coordinates, equal
+ * distances by ascending index.  The reference searches with FAISS (IVF,
+ * approximate) or KeOps argKmin (float32, exact), :497-518.
+ * mvf_mapping_occlusion: for each view-level row r (point row_point[r], image
+ * images[r]): (1 + #{j < k : seen[neighbors[point][j]][image]}) / (k + 1)
+ * (:567-596); seen [n_points][n_images] bytes; out[r * out_stride].
+ * ---------------------------------------------------------------------- */
+size_t mvf_knn_workspace_bytes(int64_t n, int32_t k);
+int mvf_knn(const float *xyz, int64_t n, int32_t k, int64_t *neighbors, void *workspace,
+            size_t workspace_bytes, void *stream);
+int mvf_mapping_occlusion(
+    const int64_t *neighbors, int32_t k_stride, int32_t k, const int64_t *row_point,
+    const int64_t *images, int64_t rows, const uint8_t *seen, int64_t n_images, float *out,
+    int32_t out_stride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -508,3 +508,93 @@ class MapImages(ImageTransform):
             torch.cat(point_ids), dense_img, torch.cat(pixels), torch.cat(features),
             num_points=int(ids.max().item()) + 1)
         return mappings, seen
+
+
+def knn(xyz, k):
+    """Indices [N, k] of the k nearest neighbours of every point among the
+    points themselves (the point first), ascending in distance; exact
+    (float64 distances, equal distances by ascending index)."""
+    device = L.require_device(xyz)
+    pos = xyz.to(device=device, dtype=torch.float32).contiguous()
+    n = pos.shape[0]
+    out = torch.empty((n, k), dtype=torch.int64, device=device)
+    lib = L.load()
+    ws = L.workspace(lib.mvf_knn_workspace_bytes(n, int(k)), device)
+    with torch.cuda.device(device):
+        L.check(lib.mvf_knn(L.ptr(pos), n, int(k), L.ptr(out), L.ptr(ws), ws.numel(),
+                            L.stream_ptr(device)))
+    return out
+
+
+class NeighborhoodBasedMappingFeatures(ImageTransform):
+    """Appends neighbourhood-based mapping features to ``images.mappings``
+    (core/data_transform/multimodal/image.py:431-612): the local surface
+    density from the radius of the k-NN ball, and the occlusion, i.e. the share
+    of the k nearest neighbours of a point that the image of a mapping also
+    sees.  ``k`` may be a list: one column per value and feature.
+
+    The neighbour search is exact (``knn``); ``use_cuda``, ``use_faiss``,
+    ``ncells`` and ``nprobes`` are accepted for signature parity (the
+    reference searches approximately with FAISS or exactly with KeOps)."""
+
+    def __init__(self, k=20, voxel=None, density=True, occlusion=True, use_cuda=False,
+                 use_faiss=True, ncells=None, nprobes=10, verbose=False):
+        self.k_list = sorted(k) if isinstance(k, list) else [k]
+        self.voxel = voxel if voxel is not None else 1
+        self.compute_density = density
+        self.compute_occlusion = occlusion
+        self.use_faiss = use_faiss
+        self.use_cuda = use_cuda
+        self.ncells = ncells
+        self.nprobes = nprobes
+        self.verbose = verbose
+        assert density or occlusion, \
+            "At least one of `density` or `occlusion` must be True."
+
+    def _process(self, data, images):
+        assert images.mappings is not None
+        in_device = images.device
+        device = L.require_device(data.pos)
+        m = images.mappings
+        xyz = data.pos.to(device=device, dtype=torch.float32).contiguous()
+        neighbors = knn(xyz, self.k_list[-1])
+        pointers = m.pointers.to(device)
+        sizes = pointers[1:] - pointers[:-1]
+        new_cols = []
+
+        if self.compute_density:
+            cols = []
+            for k in self.k_list:
+                # squared radius of the k-NN ball, density of a 2D manifold inside it
+                d2_max = ((xyz - xyz[neighbors[:, k - 1]]) ** 2).sum(dim=1)
+                v_sphere = 3.1416 * d2_max
+                voxel_density = 1 / self.voxel ** 2
+                density = ((k + 1) / v_sphere) / voxel_density
+                density[torch.where(density.isnan())] = 1
+                cols.append(density.view(-1, 1))
+            new_cols.append(torch.cat(cols, dim=1).repeat_interleave(sizes, 0))
+
+        if self.compute_occlusion:
+            n_points = xyz.shape[0]
+            image_ids = m.images.to(device).contiguous()
+            n_images = int(image_ids.max()) + 1 if image_ids.numel() else 1
+            point_ids = torch.arange(n_points, device=device).repeat_interleave(sizes).contiguous()
+            seen = torch.zeros((n_points, n_images), dtype=torch.uint8, device=device)
+            seen[point_ids, image_ids] = 1
+            rows = image_ids.shape[0]
+            occ = torch.empty((rows, len(self.k_list)), dtype=torch.float32, device=device)
+            lib = L.load()
+            with torch.cuda.device(device):
+                for c, k in enumerate(self.k_list):
+                    L.check(lib.mvf_mapping_occlusion(
+                        L.ptr(neighbors), neighbors.shape[1], int(k), L.ptr(point_ids),
+                        L.ptr(image_ids), rows, L.ptr(seen), n_images, L.ptr(occ[:, c:]),
+                        occ.shape[1], L.stream_ptr(device)))
+            new_cols.append(occ)
+
+        feats = torch.cat(new_cols, dim=1).to(in_device)
+        if not m.has_features:
+            m.features = feats
+        else:
+            m.features = torch.cat([m.features, feats.to(m.features.device)], dim=1)
+        return data, images

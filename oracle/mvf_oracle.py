@@ -858,3 +858,59 @@ def map_images(
     if timings is not None:
         timings.update(T)
     return out
+
+
+# --------------------------------------------------------------------------- #
+# data_transform/multimodal/image.py: NeighborhoodBasedMappingFeatures          #
+# --------------------------------------------------------------------------- #
+
+def knn(xyz, k):
+    """Exact k nearest neighbours of every point among the points (self first):
+    float64 squared distances of the float32 coordinates, equal distances by
+    ascending index.  The reference searches with FAISS or KeOps
+    (image.py:497-518); brute force here, for test-sized clouds."""
+    p = np.asarray(xyz, np.float32).astype(np.float64)
+    n = p.shape[0]
+    out = np.empty((n, k), np.int64)
+    for a in range(0, n, 1024):
+        d = p[a:a + 1024, None, :] - p[None, :, :]
+        d2 = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+        out[a:a + 1024] = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    return out
+
+
+def neighborhood_features(xyz, neighbors, pointers, images, k_list, voxel=1, density=True,
+                          occlusion=True):
+    """NeighborhoodBasedMappingFeatures._process, image.py:520-610: the columns
+    appended to the view-level mapping features."""
+    f32 = np.float32
+    xyz = np.asarray(xyz, f32)
+    pointers = np.asarray(pointers, np.int64)
+    images = np.asarray(images, np.int64)
+    sizes = np.diff(pointers)
+    cols = []
+    if density:
+        dens = []
+        for k in k_list:
+            d = xyz - xyz[neighbors[:, k - 1]]
+            d2_max = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            v_sphere = f32(3.1416) * d2_max
+            with np.errstate(divide="ignore", invalid="ignore"):
+                de = (f32(k + 1) / v_sphere) / f32(1 / voxel ** 2)
+            de[np.isnan(de)] = 1
+            dens.append(de.astype(f32).reshape(-1, 1))
+        cols.append(np.repeat(np.concatenate(dens, 1), sizes, axis=0))
+    if occlusion:
+        n_points = xyz.shape[0]
+        n_images = int(images.max()) + 1
+        point_ids = np.repeat(np.arange(n_points), sizes)
+        views = np.zeros((n_points, n_images), bool)
+        views[point_ids, images] = True
+        occ = []
+        for k in k_list:
+            seen = np.ones(images.shape[0], f32)
+            for i in range(k):
+                seen += views[neighbors[point_ids, i], images]
+            occ.append((seen / f32(k + 1)).reshape(-1, 1))
+        cols.append(np.concatenate(occ, 1))
+    return np.concatenate(cols, 1).astype(f32)

@@ -672,6 +672,56 @@ def gen_training():
         save(name, **arrs, **{"kw." + k: np.asarray(v) for k, v in kw.items()}, **sd0)
 
 
+# --------------------------------------------------- neighbourhood features
+class DenseLazy:
+    """Dense stand-in for the three pykeops LazyTensor operations the transform
+    uses (image.py:511-517): broadcast difference, square, sum over the
+    coordinate axis and argKmin (ascending distance, ties by index)."""
+
+    def __init__(self, t):
+        self.t = t
+
+    def __sub__(self, other):
+        return DenseLazy(self.t - other.t)
+
+    def __pow__(self, p):
+        return DenseLazy(self.t ** p)
+
+    def sum(self, dim):
+        return DenseLazy(self.t.sum(dim=dim))
+
+    def argKmin(self, k, dim):
+        return torch.argsort(self.t, dim=dim, stable=True)[:, :k]
+
+
+def gen_neighborhood_features():
+    """NeighborhoodBasedMappingFeatures (data_transform/multimodal/image.py:
+    431-612) behind MapImages-like mappings, k = [5, 20], density + occlusion."""
+    image, tr = ref["image"], ref["transforms"]
+    tr.LazyTensor = DenseLazy
+    sc = S.make_scene("c1", seed=9, n_points=3000, n_views=5)
+    xyz = sc["xyz"]
+    rng = np.random.default_rng(90)
+    n, n_img = xyz.shape[0], 5
+    sees = rng.random((n, n_img)) < 0.35
+    sees[:100] = False
+    pid, iid = np.nonzero(sees)
+    pix = rng.integers(0, 200, (pid.shape[0], 2)).astype(np.int16)
+    feat = rng.random((pid.shape[0], 2)).astype(np.float32)
+    m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n)
+    images = image.SameSettingImageData(
+        path=np.array([f"v{i}" for i in range(n_img)], dtype='O'), pos=T(sc["pos"]),
+        ref_size=(200, 200), proj_upscale=1, downscale=1, mappings=m)
+    data = _refshim.Data(pos=T(xyz), mapping_index=torch.arange(n))
+    feats_before = m.features.numpy().copy()
+    t = tr.NeighborhoodBasedMappingFeatures(k=[5, 20], voxel=0.05, density=True, occlusion=True)
+    _, out = t(data, images)
+    save("neighborhood_features", xyz=xyz, pointers=m.pointers.numpy(), images=m.images.numpy(),
+         view_pointers=m.values[1].pointers.numpy(), pixels=m.pixels.numpy(),
+         features_before=feats_before, features_after=out.mappings.features.numpy(),
+         k_list=np.array([5, 20]), voxel=0.05)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -725,6 +775,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features"]
     for w in which:
         globals()["gen_" + w]()

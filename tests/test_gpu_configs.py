@@ -303,3 +303,51 @@ def test_map_images_list_of_samples_multi_stream():
     ref = orc.map_images(sc["xyz"], np.arange(sc["xyz"].shape[0]), sc,
                          order=kdtree_order(T(sc["xyz"]), True).numpy(), ref_size=sc["img_size"], cylinder=True, exact=True, **VIS)
     check_mapping(out_list[1].mappings, ref, features_atol=1e-6)
+
+
+def test_neighborhood_mapping_features():
+    """NeighborhoodBasedMappingFeatures on the GPU: against the reference's
+    output (fixture) and, on a C1-sized cloud mapped by MapImages, against the
+    oracle (exact k-NN compared index by index, features to 1e-6)."""
+    from mvfusion.images import SameSettingImageData
+    from mvfusion.mapping import ImageMapping
+    from mvfusion.transforms import MapImages, NeighborhoodBasedMappingFeatures, knn
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "neighborhood_features.npz")))
+    m = ImageMapping.from_csr_arrays(
+        T(g["pointers"]).to(DEV), T(g["images"]).to(DEV), T(g["pixels"]).to(DEV),
+        T(g["features_before"]).to(DEV), view_pointers=T(g["view_pointers"]).to(DEV))
+    images = SameSettingImageData(pos=torch.zeros(5, 3), ref_size=(200, 200), proj_upscale=1,
+                                  mappings=m)
+    data = Data()
+    data.pos = T(g["xyz"])
+    t = NeighborhoodBasedMappingFeatures(k=[5, 20], voxel=float(g["voxel"]))
+    _, out = t(data, images)
+    np.testing.assert_allclose(npy(out.mappings.features), g["features_after"], rtol=1e-6, atol=1e-7)
+
+    # C1-sized: 100k points, mappings from MapImages
+    sc = S.make_scene("c1", seed=51)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    sub = np.random.default_rng(3).choice(N, 400, replace=False)
+    got = npy(knn(T(xyz).to(DEV), 20))
+    assert np.array_equal(got[:, 0], np.arange(N))
+    # brute-force check of a sample of the queries against all points
+    p64 = xyz.astype(np.float64)
+    d = p64[sub, None, :] - p64[None, :, :]
+    d2 = (d[:, :, 0] * d[:, :, 0] + d[:, :, 1] * d[:, :, 1]) + d[:, :, 2] * d[:, :, 2]
+    want = np.argsort(d2, axis=1, kind="stable")[:, :20]
+    assert np.array_equal(got[sub], want)
+    data, images = make_inputs(xyz, np.arange(N), sc, sc["img_size"], attrs=False)
+    tm = MapImages(method="SplattingVisibility", cylinder=True, exact=True,
+                   point_order="index", **VIS)
+    data, images = tm(data, images)
+    before = npy(images.mappings.features)
+    t = NeighborhoodBasedMappingFeatures(k=20, voxel=0.05)
+    _, images = t(data, images)
+    cols = orc.neighborhood_features(xyz, got, npy(images.mappings.pointers),
+                                     npy(images.mappings.images), [20], voxel=0.05)
+    after = npy(images.mappings.features)
+    assert after.shape[1] == before.shape[1] + 2
+    assert np.array_equal(after[:, :before.shape[1]], before)
+    np.testing.assert_allclose(after[:, before.shape[1]:], cols, rtol=1e-6, atol=1e-7)

@@ -319,3 +319,19 @@ def test_attention_variants(golden, name):
     np.testing.assert_allclose(parts["C"], g["C"].reshape(parts["C"].shape), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(parts["A"], g["A"].reshape(parts["A"].shape), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(parts["x_pool"], g["x_pool"], rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_neighborhood_features(golden):
+    """NeighborhoodBasedMappingFeatures: exact k-NN + density / occlusion
+    columns against the reference's transform (its KeOps search stood in by a
+    dense float32 argsort)."""
+    g = golden("neighborhood_features")
+    k_list = [int(k) for k in g["k_list"]]
+    nbr = orc.knn(g["xyz"], k_list[-1])
+    assert np.array_equal(nbr[:, 0], np.arange(g["xyz"].shape[0]))
+    cols = orc.neighborhood_features(g["xyz"], nbr, g["pointers"], g["images"], k_list,
+                                     voxel=float(g["voxel"]))
+    want = g["features_after"]
+    nb = g["features_before"].shape[1]
+    assert np.array_equal(want[:, :nb], g["features_before"])
+    np.testing.assert_allclose(cols, want[:, nb:], rtol=1e-6, atol=1e-7)
