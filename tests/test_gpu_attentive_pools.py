@@ -184,13 +184,16 @@ def test_heuristic_pool_and_modes():
         np.testing.assert_array_equal(out, want)
 
 
-def test_training_mode_and_cpu_inputs_raise():
-    mod = pooling.QKVBimodalCSRPool(in_main=4, in_map=4, in_mod=4)
-    x = torch.zeros(2, 4, device=DEV)
+def test_training_mode_records_a_graph_and_cpu_inputs_raise():
+    mod = pooling.QKVBimodalCSRPool(in_main=4, in_map=4, in_mod=4).to(DEV)
+    x = torch.rand(6, 4, device=DEV)
+    ptr = torch.tensor([0, 2, 2, 6], device=DEV)
+    out = mod(x[:3], x, x, ptr)                     # modules start in training mode
+    assert out.shape == (3, 4) and out.requires_grad
+    with torch.no_grad():
+        assert not mod.eval()(x[:3], x, x, ptr).requires_grad
     with pytest.raises(RuntimeError):
-        mod.to(DEV)(x, x, x, torch.tensor([0, 1, 2], device=DEV))
-    with pytest.raises(RuntimeError):
-        mod.eval()(x.cpu(), x.cpu(), x.cpu(), torch.tensor([0, 1, 2]))
+        mod.eval()(x[:3].cpu(), x.cpu(), x.cpu(), ptr.cpu())
 
 
 def test_mlp_chain_dot_epilogue():
