@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from .csr import tensor_idx
-from .mapping import ImageMapping, ImageMappingBatch
+from .mapping import ImageMapping, ImageMappingBatch, lexunique
 
 
 class SameSettingImageData:
@@ -38,7 +38,7 @@ class SameSettingImageData:
         self.downscale = downscale
         self.crop_size = tuple(crop_size) if crop_size is not None else self.ref_size
         self.crop_offsets = crop_offsets if crop_offsets is not None \
-            else torch.zeros((n, 2), dtype=torch.int64)
+            else torch.zeros((n, 2), dtype=torch.int64, device=self.pos.device)
         self.x = x
         self.mappings = mappings
         self.mask = mask
@@ -151,12 +151,12 @@ class SameSettingImageData:
         assert idx.unique().numel() == idx.shape[0], "Index must not contain duplicates."
         sel = lambda t: t[idx.to(t.device)] if t is not None else None
         return self.__class__(
-            path=self.path[np.asarray(idx.cpu())], pos=self.pos[idx],
+            path=self.path[np.asarray(idx.cpu())], pos=sel(self.pos),
             extrinsic=sel(self.extrinsic), fx=sel(self.fx), fy=sel(self.fy),
             mx=sel(self.mx), my=sel(self.my), ref_size=copy.deepcopy(self.ref_size),
             proj_upscale=copy.deepcopy(self.proj_upscale),
             downscale=copy.deepcopy(self.downscale),
-            crop_size=copy.deepcopy(self.crop_size), crop_offsets=self.crop_offsets[idx],
+            crop_size=copy.deepcopy(self.crop_size), crop_offsets=sel(self.crop_offsets),
             x=sel(self.x),
             mappings=self.mappings.select_images(idx) if self.mappings is not None else None,
             mask=self.mask.clone() if self.mask is not None else None,
@@ -182,6 +182,53 @@ class SameSettingImageData:
     @property
     def mapping_features(self):
         return self.mappings.features
+
+    def _without_mappings(self, idx=None):
+        """self[idx] (or a clone) built while the mappings are set aside: the
+        caller installs re-indexed mappings itself."""
+        kept, self.mappings = self.mappings, None
+        try:
+            return self.clone() if idx is None else self[idx]
+        finally:
+            self.mappings = kept
+
+    def select_points(self, idx, mode='pick'):
+        """Follow a new 3D sampling of the points (core/multimodal/image.py:
+        826-907): 'pick' keeps the points ``idx`` and drops the images no kept
+        point maps to; 'merge' agglomerates point i into ``idx[i]`` and keeps
+        every image.  Returns a new object."""
+        idx = tensor_idx(idx).to(self.device)
+        if self.mappings is None or idx is None or idx.shape[0] == 0:
+            return self.clone()
+        if len(self) == 0:
+            return self.clone()
+        if mode == 'pick':
+            mappings = self.mappings.select_points(idx, mode=mode)
+            seen_image_idx = lexunique(mappings.images) if mappings.num_items > 0 \
+                else torch.empty(0, dtype=torch.int64)
+            images = self._without_mappings(seen_image_idx)
+            images.mappings = mappings.select_images(seen_image_idx)
+        elif mode == 'merge':
+            images = self.clone()
+            if not idx.shape[0] == self.num_points > 0:
+                return images
+            if not torch.arange(int(idx.max()) + 1, device=idx.device).equal(idx.unique()):
+                return images
+            images.mappings = images.mappings.select_points(idx, mode=mode)
+        else:
+            raise ValueError(f"Unknown point selection mode '{mode}'.")
+        return images
+
+    def select_views(self, view_mask):
+        """Keep the views of the boolean ``view_mask`` over the view-level rows
+        of the mappings; images left without a view are dropped
+        (core/multimodal/image.py:909-950).  Returns a new object."""
+        if self.mappings is None or view_mask is None or torch.all(view_mask) or len(self) == 0:
+            return self.clone()
+        mappings, seen_image_idx = self.mappings.select_views(view_mask)
+        images = self._without_mappings(seen_image_idx)
+        images.mappings = mappings
+        return images
 
     def get_mapped_features(self, interpolate=False):
         """Features of ``self.x`` [V, C, H, W] at the mapped pixels, one row per
@@ -281,6 +328,15 @@ class ImageData:
     @staticmethod
     def get_batch_type():
         return ImageBatch
+
+    def select_points(self, idx, mode='pick'):
+        """core/multimodal/image.py:1501-1503"""
+        return self.__class__([im.select_points(idx, mode=mode) for im in self])
+
+    def select_views(self, view_mask_list):
+        """core/multimodal/image.py:1505-1511"""
+        assert isinstance(view_mask_list, list) and len(view_mask_list) == len(self)
+        return self.__class__([im.select_views(m) for im, m in zip(self, view_mask_list)])
 
     def __len__(self):
         return len(self._list)

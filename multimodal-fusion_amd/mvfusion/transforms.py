@@ -598,3 +598,95 @@ class NeighborhoodBasedMappingFeatures(ImageTransform):
         else:
             m.features = torch.cat([m.features, feats.to(m.features.device)], dim=1)
         return data, images
+
+
+MAPPING_KEY = 'mapping_index'
+
+
+class SelectMappingFromPointId(ImageTransform):
+    """Keeps the mappings of the points of ``data`` (their ``mapping_index``)
+    and the images those points are seen in, then renumbers the point ids
+    (core/data_transform/multimodal/image.py:615-644)."""
+
+    def __init__(self):
+        self.key = MAPPING_KEY
+
+    def _process(self, data, images):
+        assert hasattr(data, self.key)
+        assert images.mappings is not None
+        images = images.select_points(getattr(data, self.key), mode='pick')
+        setattr(data, self.key, torch.arange(data.pos.shape[0], device=images.device))
+        return data, images
+
+
+class DropImagesOutsideDataBoundingBox(ImageTransform):
+    """Drops the images whose position is outside the bounding box of the
+    points (+ margin) (core/data_transform/multimodal/image.py:647-666)."""
+
+    def __init__(self, margin=0, ignore_z=False):
+        self.margin = margin
+        self.ignore_z = ignore_z
+
+    def _process(self, data, images):
+        b_min = data.pos.min(dim=0).values - self.margin / 2
+        b_max = data.pos.max(dim=0).values + self.margin / 2
+        pos = images.pos.to(b_min.device)
+        mask = torch.logical_and(b_min < pos, pos < b_max)
+        mask = mask[:, 0] * mask[:, 1] if self.ignore_z else mask[:, 0] * mask[:, 1] * mask[:, 2]
+        return data, images[mask]
+
+
+class PickKImages(ImageTransform):
+    """Keeps K images, at random or one every K in their order
+    (core/data_transform/multimodal/image.py:689-710)."""
+
+    def __init__(self, k, random=False, replace=False):
+        self.k = k
+        self.random = random
+        self.replace = replace
+
+    def _process(self, data, images):
+        if self.random:
+            idx = torch.from_numpy(np.random.choice(
+                range(images.num_views), size=self.k, replace=self.replace))
+        else:
+            idx = slice(0, images.num_views, self.k)
+        return data, images[idx]
+
+
+class PickImagesFromMappingArea(ImageTransform):
+    """Drops the images whose mappings cover less than ``area_ratio`` of the
+    image (pixel count, or bounding box of the mapped pixels with
+    ``use_bbox``), keeps at most ``n_max`` of the others, largest first
+    (core/data_transform/multimodal/image.py:713-762)."""
+
+    def __init__(self, area_ratio=0.02, n_max=None, n_min=0, use_bbox=False):
+        self.area_ratio = area_ratio
+        self.n_max = n_max if n_max is not None and n_max >= 1 else None
+        self.n_min = n_min if n_max is not None and n_min >= 0 else 0
+        self.use_bbox = use_bbox
+
+    def _process(self, data, images):
+        assert images.mappings is not None, "No mappings found in images."
+        m = images.mappings
+        threshold = images.img_size[0] * images.img_size[1] * self.area_ratio
+        sizes = m.values[1].pointers[1:] - m.values[1].pointers[:-1]
+        pixel_idx = m.images.repeat_interleave(sizes)
+        n_img = int(pixel_idx.max()) + 1 if pixel_idx.numel() else 0
+        if not self.use_bbox:
+            areas = torch.zeros(n_img, device=pixel_idx.device).index_add_(
+                0, pixel_idx, torch.ones(pixel_idx.shape[0], device=pixel_idx.device))
+        else:
+            pix = m.pixels.int()
+            idx2 = pixel_idx[:, None].expand(-1, 2)
+            xy_min = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
+                0, idx2, pix, 'amin', include_self=False)
+            xy_max = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
+                0, idx2, pix, 'amax', include_self=False)
+            areas = (xy_max[:, 0] - xy_min[:, 0]) * (xy_max[:, 1] - xy_min[:, 1])
+        n_max = images.num_views if self.n_max is None else self.n_max
+        idx = areas.argsort().flip(0)
+        idx = idx[areas[idx] > threshold][:n_max]
+        if idx.shape[0] == 0 and images.num_views > 0 and self.n_min > 0:
+            idx = idx[:self.n_min]
+        return data, images[idx]

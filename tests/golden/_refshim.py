@@ -84,10 +84,21 @@ def scatter_mean(src, index, dim=0, dim_size=None):
     return out / cnt.view((-1,) + (1,) * (src.dim() - 1))
 
 
+def scatter_add(src, index, dim=0, dim_size=None):
+    """torch_scatter.scatter_add on dim 0."""
+    assert dim == 0
+    n = int(index.max()) + 1 if dim_size is None else dim_size
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add_(0, index, src)
+
+
 def _scatter_minmax(src, index, dim=0, dim_size=None, is_min=True):
     n = int(index.max()) + 1 if dim_size is None else dim_size
     if src.dim() == 1:
-        fill = float("inf") if is_min else float("-inf")
+        if src.dtype.is_floating_point:
+            fill = float("inf") if is_min else float("-inf")
+        else:
+            fill = torch.iinfo(src.dtype).max if is_min else torch.iinfo(src.dtype).min
         out = torch.full((n,), fill, dtype=src.dtype)
         arg = torch.full((n,), src.shape[0], dtype=torch.long)
         for i in range(src.shape[0]):
@@ -194,7 +205,7 @@ def load_reference():
     if _loaded:
         return _loaded
     _mod("numba", njit=_njit)
-    _mod("torch_scatter", segment_csr=segment_csr, scatter_mean=scatter_mean,
+    _mod("torch_scatter", segment_csr=segment_csr, scatter_mean=scatter_mean, scatter_add=scatter_add,
          scatter_min=lambda s, i, dim=0, dim_size=None: _scatter_minmax(s, i, dim, dim_size, True),
          scatter_max=lambda s, i, dim=0, dim_size=None: _scatter_minmax(s, i, dim, dim_size, False))
     _mod("pykeops")

@@ -722,6 +722,69 @@ def gen_neighborhood_features():
          k_list=np.array([5, 20]), voxel=0.05)
 
 
+# ------------------------------------------------- image-selection transforms
+def gen_image_selection():
+    """SameSettingImageData.select_points / select_views and the transforms
+    SelectMappingFromPointId, DropImagesOutsideDataBoundingBox,
+    PickImagesFromMappingArea (core/multimodal/image.py:826-950,
+    core/data_transform/multimodal/image.py:615-762) on one sample."""
+    image, tr = ref["image"], ref["transforms"]
+    rng = np.random.default_rng(71)
+    n, n_img, size = 600, 6, 64
+    sees = rng.random((n, n_img)) < np.array([0.5, 0.02, 0.3, 0.0, 0.4, 0.05])
+    sees[3, 3] = True                          # image 3 is seen by a single point
+    pid, iid = np.nonzero(sees)
+    pix = rng.integers(0, size, (pid.shape[0], 2)).astype(np.int16)
+    feat = rng.random((pid.shape[0], 2)).astype(np.float32)
+    pos_img = (rng.random((n_img, 3)) * 4 - 1).astype(np.float64)
+    xyz = rng.random((n, 3)).astype(np.float32) * 2
+
+    def fresh():
+        m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n)
+        return image.SameSettingImageData(
+            path=np.array([f"v{i}" for i in range(n_img)], dtype='O'), pos=T(pos_img),
+            ref_size=(size, size), proj_upscale=1, downscale=1, mappings=m)
+
+    base = fresh()
+    arrs = dict(xyz=xyz, pos_img=pos_img, size=size)
+    arrs.update(mapping_arrays(base.mappings, "in_"))
+
+    def record(tag, im):
+        arrs[tag + "_pos"] = im.pos.numpy()
+        arrs[tag + "_path"] = np.array([str(p) for p in im.path])
+        arrs.update(mapping_arrays(im.mappings, tag + "_"))
+
+    pick = rng.permutation(n)[:150].astype(np.int64)
+    pick[0] = 3
+    arrs["pick"] = pick
+    record("pick", fresh().select_points(T(pick), mode='pick'))
+    n_vox = 200
+    merge = np.concatenate([np.arange(n_vox), rng.integers(0, n_vox, n - n_vox)]).astype(np.int64)
+    merge = merge[rng.permutation(n)]
+    arrs["merge"] = merge
+    record("merge", fresh().select_points(T(merge), mode='merge'))
+    im = fresh()
+    mask = rng.random(im.mappings.num_items) < 0.6
+    mask[im.mappings.images.numpy() == 2] = False
+    arrs["view_mask"] = mask
+    record("views", im.select_views(T(mask)))
+    # transforms
+    sub = np.sort(rng.permutation(n)[:250]).astype(np.int64)
+    data = _refshim.Data(pos=T(xyz[sub]), mapping_index=T(sub))
+    d2, out = tr.SelectMappingFromPointId()(data, fresh())
+    arrs["sub"] = sub
+    arrs["smfp_index"] = d2.mapping_index.numpy()
+    record("smfp", out)
+    data = _refshim.Data(pos=T(xyz), mapping_index=torch.arange(n))
+    _, out = tr.DropImagesOutsideDataBoundingBox(margin=0.5)(data, fresh())
+    record("bbox", out)
+    for tag, kw in (("area", dict(area_ratio=0.02, n_max=3)),
+                    ("area_bbox", dict(area_ratio=0.3, use_bbox=True))):
+        _, out = tr.PickImagesFromMappingArea(**kw)(data, fresh())
+        record(tag, out)
+    save("image_selection", **arrs)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -775,6 +838,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection"]
     for w in which:
         globals()["gen_" + w]()

@@ -287,3 +287,29 @@ def test_bimodal_pool_backward(mode):
     with torch.no_grad():
         assert not segment_csr(xg, T(ptr), reduce=mode).requires_grad
     assert not segment_csr(T(x), T(ptr), reduce=mode).requires_grad
+
+
+def test_images_select_points_merge_golden(golden):
+    """SameSettingImageData.select_points(mode='merge') (the re-indexing after a
+    strided 3D convolution) on device tensors against the reference."""
+    from mvfusion.images import SameSettingImageData
+    g = golden("image_selection")
+    n_img, size = g["pos_img"].shape[0], int(g["size"])
+    m = M.ImageMapping.from_csr_arrays(
+        T(g["in_pointers"]), T(g["in_images"]), T(g["in_pixels"]), T(g["in_features"]),
+        view_pointers=T(g["in_view_pointers"]))
+    images = SameSettingImageData(pos=T(g["pos_img"]), ref_size=(size, size), proj_upscale=1,
+                                  mappings=m)
+    out = images.select_points(T(g["merge"]), mode="merge")
+    assert out.num_views == n_img
+    mo = out.mappings
+    assert np.array_equal(mo.pointers.cpu().numpy(), g["merge_pointers"])
+    assert np.array_equal(mo.images.cpu().numpy(), g["merge_images"])
+    vp = g["merge_view_pointers"]
+    assert np.array_equal(mo.values[1].pointers.cpu().numpy(), vp)
+    assert np.array_equal(mo.pixels.cpu().numpy(), canonical_pixels(vp, g["merge_pixels"]))
+    np.testing.assert_allclose(mo.features.cpu().numpy(), g["merge_features"], rtol=1e-6, atol=1e-7)
+    # 'pick' on the device gives what the host-side test checks on the CPU
+    pick = images.select_points(T(g["pick"]), mode="pick")
+    assert np.array_equal(pick.mappings.pointers.cpu().numpy(), g["pick_pointers"])
+    assert np.array_equal(pick.pos.cpu().numpy(), g["pick_pos"])

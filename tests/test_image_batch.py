@@ -101,3 +101,59 @@ def test_image_batch(golden):
             assert torch.equal(im.mappings.pixels, src.mappings.pixels)
             assert torch.equal(im.mappings.features, src.mappings.features)
             assert torch.equal(im.pos, src.pos)
+
+
+# --------------------------------------------------------- image selection
+class _Data:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _sample(g):
+    n_img = g["pos_img"].shape[0]
+    size = int(g["size"])
+    return SameSettingImageData(
+        path=[f"v{i}" for i in range(n_img)], pos=T(g["pos_img"]), ref_size=(size, size),
+        proj_upscale=1, downscale=1, mappings=mapping(g, "in_"))
+
+
+def _same_images(im, g, tag):
+    assert np.array_equal(im.pos.numpy(), g[tag + "_pos"]), tag
+    assert [str(p) for p in im.path] == [str(p) for p in g[tag + "_path"]], tag
+    same(im.mappings, g, tag + "_")
+
+
+def test_select_points_and_views_on_images(golden):
+    """SameSettingImageData.select_points ('pick' drops unseen images, 'merge'
+    keeps them) and select_views.  The mappings' own select_points runs on the
+    HIP device, so this test only covers 'pick' and the views here; 'merge'
+    is covered on the GPU."""
+    g = golden("image_selection")
+    _same_images(_sample(g).select_points(T(g["pick"]), mode="pick"), g, "pick")
+    _same_images(_sample(g).select_views(T(g["view_mask"])), g, "views")
+    im = _sample(g)
+    assert im.select_views(torch.ones(im.mappings.num_items, dtype=torch.bool)).num_views == im.num_views
+    both = ImageData([_sample(g), _sample(g)]).select_points(T(g["pick"]), mode="pick")
+    assert len(both) == 2
+    _same_images(both[1], g, "pick")
+
+
+def test_image_selection_transforms(golden):
+    from mvfusion.transforms import (DropImagesOutsideDataBoundingBox, PickImagesFromMappingArea,
+                                     PickKImages, SelectMappingFromPointId)
+    g = golden("image_selection")
+    n = g["xyz"].shape[0]
+    sub = g["sub"]
+    data = _Data(pos=T(g["xyz"][sub]), mapping_index=T(sub))
+    d2, out = SelectMappingFromPointId()(data, _sample(g))
+    assert np.array_equal(d2.mapping_index.numpy(), g["smfp_index"])
+    _same_images(out, g, "smfp")
+    data = _Data(pos=T(g["xyz"]), mapping_index=torch.arange(n))
+    _, out = DropImagesOutsideDataBoundingBox(margin=0.5)(data, _sample(g))
+    _same_images(out, g, "bbox")
+    _, out = PickImagesFromMappingArea(area_ratio=0.02, n_max=3)(data, _sample(g))
+    _same_images(out, g, "area")
+    _, out = PickImagesFromMappingArea(area_ratio=0.3, use_bbox=True)(data, _sample(g))
+    _same_images(out, g, "area_bbox")
+    _, out = PickKImages(2)(data, _sample(g))
+    assert out.num_views == 3 and [str(p) for p in out.path] == ["v0", "v2", "v4"]
