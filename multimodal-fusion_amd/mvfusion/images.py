@@ -35,14 +35,65 @@ class SameSettingImageData:
         self.fx, self.fy, self.mx, self.my = fx, fy, mx, my
         self.ref_size = tuple(ref_size)
         self.proj_upscale = proj_upscale
-        self.downscale = downscale
+        self._downscale = downscale
         self.crop_size = tuple(crop_size) if crop_size is not None else self.ref_size
         self.crop_offsets = crop_offsets if crop_offsets is not None \
             else torch.zeros((n, 2), dtype=torch.int64, device=self.pos.device)
+        self._x = None
         self.x = x
         self.mappings = mappings
         self.mask = mask
         self.visibility = visibility
+
+    @property
+    def downscale(self):
+        """Scale of the current feature map with respect to ``crop_size``
+        (core/multimodal/image.py:722-744)."""
+        return self._downscale
+
+    @downscale.setter
+    def downscale(self, scale):
+        assert (self._x is None and getattr(self, 'mappings', None) is None) \
+            or self._downscale == scale, \
+            "Can't directly edit 'downscale' if 'x' or 'mappings' are not both None. " \
+            "Setting 'x' will automatically adjust the scale."
+        assert scale >= 1, f"Expected scalar larger than 1 but got {scale} instead."
+        self._downscale = scale
+
+    @property
+    def x(self):
+        """Feature maps [V, C, H, W] (core/multimodal/image.py:746-787)."""
+        return self._x
+
+    @x.setter
+    def x(self, x):
+        """Setting feature maps of another resolution adjusts ``downscale`` (the
+        larger of the two axis ratios), so that the mappings can follow."""
+        if x is None:
+            self._x = None
+            return
+        assert isinstance(x, torch.Tensor) and x.shape[0] == self.num_views, \
+            f"Expected a tensor of shape ({self.num_views}, :, {self.img_size[1]}, " \
+            f"{self.img_size[0]}) but got {tuple(x.shape)} instead."
+        scale = max(self.img_size[0] / x.shape[3], self.img_size[1] / x.shape[2])
+        self._downscale = self._downscale * scale
+        self._x = x
+
+    def update_cropping(self, crop_size, crop_offsets):
+        """Crop the feature maps and the mappings with respect to the current
+        ``img_size``; ``crop_size`` / ``crop_offsets`` are kept with respect to
+        ``ref_size`` (core/multimodal/image.py:688-720).  In place."""
+        crop_offsets = crop_offsets.long()
+        self.crop_size = tuple(int(v * self.downscale) for v in crop_size)
+        self.crop_offsets = (self.crop_offsets + crop_offsets.to(self.crop_offsets.device)
+                             * self.downscale).long()
+        if self._x is not None:
+            self._x = torch.cat([
+                im[:, o[1]:o[1] + crop_size[1], o[0]:o[0] + crop_size[0]].unsqueeze(0)
+                for im, o in zip(self._x, crop_offsets.tolist())])
+        if self.mappings is not None:
+            self.mappings = self.mappings.crop(crop_size, crop_offsets)
+        return self
 
     # the reference exposes these as computed properties
     @property
@@ -79,13 +130,13 @@ class SameSettingImageData:
     def clone(self):
         """Shallow copy, except for x and mappings (image.py:1174-1183)."""
         out = copy.copy(self)
-        out.x = self.x.clone() if self.x is not None else None
+        out._x = self._x.clone() if self._x is not None else None
         out.mappings = self.mappings.clone() if self.mappings is not None else None
         return out
 
     def to(self, device):
         out = copy.copy(self)
-        for k in self._torch_keys + ('x', 'mappings', 'mask'):
+        for k in self._torch_keys + ('_x', 'mappings', 'mask'):
             v = getattr(self, k)
             setattr(out, k, v.to(device) if v is not None else None)
         return out

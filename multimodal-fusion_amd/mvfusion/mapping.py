@@ -285,6 +285,31 @@ class ImageMapping(CSRData):
             up = (pix.float() * ratio).long()
         return self._with_pixels(up.type(pix.dtype))
 
+    def crop(self, crop_size, crop_offsets):
+        """Pixel coordinates after cropping every image at its own offset
+        [n_images, 2] to a common ``crop_size`` (W, H); mappings that fall
+        outside are dropped and the nested CSR is rebuilt
+        (core/multimodal/image.py:2289-2352).  As in the reference, the pixels
+        take the integer type of the offsets, and when *no* pixel is left inside
+        the box the mappings are returned shifted but otherwise whole."""
+        assert tuple(crop_offsets.shape) == (self.images.unique().numel(), 2), \
+            f"Expected crop_offsets to have shape {(self.images.unique().numel(), 2)} " \
+            f"but got shape {tuple(crop_offsets.shape)} instead."
+        sizes = self.values[1].pointers[1:] - self.values[1].pointers[:-1]
+        image_ids = self.images.repeat_interleave(sizes)
+        pixels = self.pixels - crop_offsets.to(self.device)[image_ids]
+        box = torch.tensor(list(crop_size), device=self.device)
+        inside = torch.where((pixels >= 0).all(dim=1) & (pixels < box).all(dim=1))[0]
+        if inside.shape[0] == 0:
+            return self._with_pixels(pixels)
+        point_ids = torch.arange(self.num_groups, device=self.device).repeat_interleave(
+            self.pointers[1:] - self.pointers[:-1]).repeat_interleave(sizes)
+        features = self.features.repeat_interleave(sizes, dim=0)[inside] \
+            if self.has_features else None
+        return ImageMapping.from_dense(
+            point_ids[inside], image_ids[inside], pixels[inside], features,
+            num_points=self.num_groups)
+
     def debug(self):
         super(ImageMapping, self).debug()
         assert len(self.values) == 2 or self.has_features

@@ -785,6 +785,42 @@ def gen_image_selection():
     save("image_selection", **arrs)
 
 
+def gen_cropping():
+    """ImageMapping.crop, SameSettingImageData.update_cropping and the
+    downscale bookkeeping of the x setter (core/multimodal/image.py:688-787,
+    2289-2352)."""
+    image = ref["image"]
+    rng = np.random.default_rng(81)
+    n, n_img, W, H = 400, 4, 64, 48
+    sees = rng.random((n, n_img)) < 0.4
+    pid, iid = np.nonzero(sees)
+    pix = np.stack([rng.integers(0, W, pid.shape[0]), rng.integers(0, H, pid.shape[0])], 1).astype(np.int16)
+    feat = rng.random((pid.shape[0], 2)).astype(np.float32)
+    x = rng.random((n_img, 3, H, W)).astype(np.float32)
+    m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n)
+    arrs = dict(x=x, size=np.array([W, H]))
+    arrs.update(mapping_arrays(m, "in_"))
+    images = image.SameSettingImageData(
+        path=np.array([f"v{i}" for i in range(n_img)], dtype='O'), pos=T(rng.random((n_img, 3))),
+        ref_size=(W, H), proj_upscale=1, downscale=1, mappings=m, x=T(x))
+    crop_size = (32, 24)
+    offsets = np.stack([rng.integers(0, W - 32, n_img), rng.integers(0, H - 24, n_img)], 1).astype(np.int64)
+    arrs.update(crop_size=np.array(crop_size), crop_offsets=offsets)
+    images.update_cropping(crop_size, T(offsets))
+    arrs.update(mapping_arrays(images.mappings, "crop_"))
+    arrs.update(crop_x=images.x.numpy(), crop_state_size=np.array(images.crop_size),
+                crop_state_offsets=images.crop_offsets.numpy(), crop_img_size=np.array(images.img_size))
+    # a feature map at half resolution: the setter doubles the downscale
+    images.x = T(images.x.numpy()[:, :, ::2, ::2].copy())
+    arrs.update(half_downscale=float(images.downscale), half_img_size=np.array(images.img_size))
+    # a crop box no mapping falls into: pixels shifted, nothing dropped
+    far = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n)
+    out = far.crop((4, 4), T(np.full((n_img, 2), 1000, np.int64)))
+    arrs["far_pixels"] = out.pixels.numpy()
+    arrs["far_pointers"] = out.pointers.numpy()
+    save("cropping", **arrs)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -838,6 +874,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping"]
     for w in which:
         globals()["gen_" + w]()

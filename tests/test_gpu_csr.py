@@ -313,3 +313,42 @@ def test_images_select_points_merge_golden(golden):
     pick = images.select_points(T(g["pick"]), mode="pick")
     assert np.array_equal(pick.mappings.pointers.cpu().numpy(), g["pick_pointers"])
     assert np.array_equal(pick.pos.cpu().numpy(), g["pick_pos"])
+
+
+def test_cropping_golden(golden):
+    """ImageMapping.crop / SameSettingImageData.update_cropping and the
+    downscale bookkeeping when feature maps of another resolution are set."""
+    from mvfusion.images import SameSettingImageData
+    g = golden("cropping")
+    W, H = (int(v) for v in g["size"])
+    n_img = g["x"].shape[0]
+    m = M.ImageMapping.from_csr_arrays(
+        T(g["in_pointers"]), T(g["in_images"]), T(g["in_pixels"]), T(g["in_features"]),
+        view_pointers=T(g["in_view_pointers"]))
+    images = SameSettingImageData(pos=torch.zeros(n_img, 3, device=DEV), ref_size=(W, H),
+                                  proj_upscale=1, downscale=1, mappings=m, x=T(g["x"]))
+    images.update_cropping(tuple(int(v) for v in g["crop_size"]), T(g["crop_offsets"]))
+    mo = images.mappings
+    assert np.array_equal(mo.pointers.cpu().numpy(), g["crop_pointers"])
+    assert np.array_equal(mo.images.cpu().numpy(), g["crop_images"])
+    vp = g["crop_view_pointers"]
+    assert np.array_equal(mo.values[1].pointers.cpu().numpy(), vp)
+    assert mo.pixels.dtype == torch.int64
+    assert np.array_equal(mo.pixels.cpu().numpy(), canonical_pixels(vp, g["crop_pixels"]))
+    np.testing.assert_allclose(mo.features.cpu().numpy(), g["crop_features"], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(images.x.cpu().numpy(), g["crop_x"])
+    assert tuple(images.crop_size) == tuple(g["crop_state_size"])
+    assert np.array_equal(images.crop_offsets.cpu().numpy(), g["crop_state_offsets"])
+    assert tuple(images.img_size) == tuple(g["crop_img_size"])
+    images.x = images.x[:, :, ::2, ::2].contiguous()
+    assert float(images.downscale) == float(g["half_downscale"])
+    assert tuple(images.img_size) == tuple(g["half_img_size"])
+    # the mapped features follow the new resolution
+    feats = images.get_mapped_features()
+    assert feats.shape == (mo.pixels.shape[0], g["x"].shape[1])
+    far = M.ImageMapping.from_csr_arrays(
+        T(g["in_pointers"]), T(g["in_images"]), T(g["in_pixels"]), T(g["in_features"]),
+        view_pointers=T(g["in_view_pointers"])).crop(
+            (4, 4), torch.full((n_img, 2), 1000, dtype=torch.int64, device=DEV))
+    assert np.array_equal(far.pointers.cpu().numpy(), g["far_pointers"])
+    assert np.array_equal(far.pixels.cpu().numpy(), g["far_pixels"])
