@@ -372,15 +372,19 @@ int mvf_segment_pick(
  * mvf_knn: the k <= 64 nearest neighbours of every point among the n points
  * (the point itself included, first), neighbors [n][k] ascending in distance;
  * exact: float64 squared distances of the float32 coordinates, equal
- * distances by ascending index.  The reference searches with FAISS (IVF,
+ * distances by ascending id.  ids [n] (NULL = row index) names the rows: the
+ * output holds ids, row r of neighbors belongs to row r of xyz.  Any row order
+ * gives the same result; rows sorted along a space-filling curve make it
+ * several times faster.  box_lo / box_hi [ceil(n / 256)][3] (or both NULL):
+ * bounding boxes of the rows 256 c .. 256 c + 255; with them, chunks that are
+ * too far from a block of queries to matter are skipped.  The reference searches with FAISS (IVF,
  * approximate) or KeOps argKmin (float32, exact), :497-518.
  * mvf_mapping_occlusion: for each view-level row r (point row_point[r], image
  * images[r]): (1 + #{j < k : seen[neighbors[point][j]][image]}) / (k + 1)
  * (:567-596); seen [n_points][n_images] bytes; out[r * out_stride].
  * ---------------------------------------------------------------------- */
-size_t mvf_knn_workspace_bytes(int64_t n, int32_t k);
-int mvf_knn(const float *xyz, int64_t n, int32_t k, int64_t *neighbors, void *workspace,
-            size_t workspace_bytes, void *stream);
+int mvf_knn(const float *xyz, const int64_t *ids, int64_t n, int32_t k, const float *box_lo,
+            const float *box_hi, int64_t *neighbors, void *stream);
 int mvf_mapping_occlusion(
     const int64_t *neighbors, int32_t k_stride, int32_t k, const int64_t *row_point,
     const int64_t *images, int64_t rows, const uint8_t *seen, int64_t n_images, float *out,

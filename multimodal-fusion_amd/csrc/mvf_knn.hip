@@ -5,12 +5,21 @@
 //
 // k-NN: brute force, 256 queries per block, one query per thread with its K
 // best (distance, index) pairs kept sorted in registers; the candidate is the
-// same for all lanes and arrives through scalar loads.  Distances are the float64 sums dx*dx + dy*dy + dz*dz of the
-// float32 coordinates (differences and squares are exact in float64), so the
-// ranking is that of exact arithmetic up to the last rounding of the sum, and
-// equal distances rank by ascending index: the result does not depend on the
-// traversal order.  The point itself is part of the candidates, as in the
-// reference (its own distance 0 comes first).
+// same for all lanes and arrives through scalar loads.  Distances are the
+// float64 sums dx*dx + dy*dy + dz*dz of the float32 coordinates (differences
+// and squares are exact in float64), so the ranking is that of exact
+// arithmetic up to the last rounding of the sum, and equal distances rank by
+// ascending point id: the result does not depend on the traversal order.  The
+// point itself is part of the candidates, as in the reference (its own
+// distance 0 comes first).
+//
+// The expensive part is the sorted insertion, which a wave executes whenever
+// one of its lanes accepts a candidate.  The caller therefore passes the points
+// in a space-filling-curve order (ids = original index of each row): the
+// queries of a block are neighbours in space, the block scans the candidates
+// next to it in that order first, and after this window the lists are close to
+// final, so that the scan of the other candidates rarely inserts -- and most
+// of them are not scanned at all: see the chunk boxes of knn_kernel.
 #include "mvf_common.h"
 
 namespace mvf {
@@ -34,27 +43,13 @@ __device__ __forceinline__ void knn_insert(double (&bd)[K], int (&bi)[K], double
     if (!placed) { bd[0] = d; bi[0] = j; }
 }
 
-// The candidates are cut into gridDim.y slices so that small clouds still fill
-// the chip; slice s of query q leaves its K best pairs, sorted, in
-// part_d / part_i [q][s][K] (written straight to neighbors when there is one
-// slice only).
+constexpr int KNN_WINDOW = 2048;      // candidates scanned first, on each side of the block
+
 template <int K>
-__global__ __launch_bounds__(256) void knn_kernel(
-    const float *__restrict__ xyz, i64 n, int k, i64 slice_len, double *__restrict__ part_d,
-    int *__restrict__ part_i, i64 *__restrict__ neighbors)
+__device__ __forceinline__ void knn_scan(
+    const float *__restrict__ xyz, const i64 *__restrict__ ids, i64 lo, i64 hi, double qx, double qy,
+    double qz, double (&bd)[K], int (&bi)[K])
 {
-    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    const bool live = q < n;
-    const i64 qs = live ? q : n - 1;
-    const double qx = (double)xyz[3 * qs], qy = (double)xyz[3 * qs + 1], qz = (double)xyz[3 * qs + 2];
-    double bd[K];
-    int bi[K];
-#pragma unroll
-    for (int t = 0; t < K; ++t) { bd[t] = 1.0e300; bi[t] = 0x7fffffff; }
-    const i64 lo = (i64)blockIdx.y * slice_len;
-    const i64 hi = lo + slice_len < n ? lo + slice_len : n;
-    // the candidate is the same for every lane: its coordinates come through
-    // scalar loads, eight candidates requested at a time
     for (i64 base = lo; base < hi; base += 8) {
         double cx[8], cy[8], cz[8];
 #pragma unroll
@@ -66,43 +61,68 @@ __global__ __launch_bounds__(256) void knn_kernel(
         for (int u = 0; u < 8; ++u) {
             const double dx = qx - cx[u], dy = qy - cy[u], dz = qz - cz[u];
             const double d = dx * dx + dy * dy + dz * dz;
-            const int j = (int)(base + u);
-            if (base + u < hi && knn_before(d, j, bd[K - 1], bi[K - 1])) knn_insert<K>(bd, bi, d, j);
+            if (base + u < hi && d <= bd[K - 1]) {
+                const int j = ids ? (int)ids[base + u] : (int)(base + u);
+                if (knn_before(d, j, bd[K - 1], bi[K - 1])) knn_insert<K>(bd, bi, d, j);
+            }
         }
     }
-    if (!live) return;
-    if (gridDim.y == 1) {
-#pragma unroll
-        for (int t = 0; t < K; ++t)
-            if (t < k) neighbors[(size_t)q * k + t] = (i64)bi[t];
-        return;
-    }
-    const size_t o = ((size_t)q * gridDim.y + blockIdx.y) * K;
-#pragma unroll
-    for (int t = 0; t < K; ++t) { part_d[o + t] = bd[t]; part_i[o + t] = bi[t]; }
 }
 
-// Merge of the slices' sorted lists of one query: one thread per query.
+// Rows come in chunks of 256 (= the queries of a block) with bounding boxes
+// box_lo / box_hi [chunks][3] (NULL: no culling).  After the window the block
+// knows the largest k-th distance of its queries; a chunk whose box is farther
+// than that from the box of the queries cannot change any list and is skipped.
 template <int K>
-__global__ __launch_bounds__(256) void knn_merge_kernel(
-    const double *__restrict__ part_d, const int *__restrict__ part_i, i64 n, int k, int slices,
+__global__ __launch_bounds__(256) void knn_kernel(
+    const float *__restrict__ xyz, const i64 *__restrict__ ids, i64 n, int k,
+    const float *__restrict__ box_lo, const float *__restrict__ box_hi,
     i64 *__restrict__ neighbors)
 {
+    __shared__ unsigned long long s_worst;
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n) return;
+    const bool live = q < n;
+    const i64 qs = live ? q : n - 1;
+    const double qx = (double)xyz[3 * qs], qy = (double)xyz[3 * qs + 1], qz = (double)xyz[3 * qs + 2];
     double bd[K];
     int bi[K];
 #pragma unroll
     for (int t = 0; t < K; ++t) { bd[t] = 1.0e300; bi[t] = 0x7fffffff; }
-    for (int s = 0; s < slices; ++s) {
-        const size_t o = ((size_t)q * slices + s) * K;
-        for (int t = 0; t < K; ++t) {
-            const double d = part_d[o + t];
-            const int j = part_i[o + t];
-            if (!knn_before(d, j, bd[K - 1], bi[K - 1])) break;     // the list is sorted
-            knn_insert<K>(bd, bi, d, j);
+    if (threadIdx.x == 0) s_worst = 0ull;
+    const i64 chunks = (n + 255) / 256;
+    const i64 c0 = blockIdx.x;
+    const i64 cw_lo = c0 > KNN_WINDOW / 256 ? c0 - KNN_WINDOW / 256 : 0;
+    const i64 cw_hi = c0 + 1 + KNN_WINDOW / 256 < chunks ? c0 + 1 + KNN_WINDOW / 256 : chunks;
+    const i64 w_lo = cw_lo * 256, w_hi = cw_hi * 256 < n ? cw_hi * 256 : n;
+    knn_scan<K>(xyz, ids, w_lo, w_hi, qx, qy, qz, bd, bi);
+    if (box_lo == nullptr) {
+        knn_scan<K>(xyz, ids, 0, w_lo, qx, qy, qz, bd, bi);
+        knn_scan<K>(xyz, ids, w_hi, n, qx, qy, qz, bd, bi);
+    } else {
+        // positive doubles order like their bit patterns
+        __syncthreads();
+        atomicMax(&s_worst, (unsigned long long)__double_as_longlong(bd[K - 1]));
+        __syncthreads();
+        const double worst = __longlong_as_double((long long)s_worst);
+        double ql[3], qh[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ql[a] = (double)box_lo[3 * c0 + a]; qh[a] = (double)box_hi[3 * c0 + a]; }
+        for (i64 c = 0; c < chunks; ++c) {
+            if (c >= cw_lo && c < cw_hi) continue;
+            double gap2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double lo = (double)box_lo[3 * c + a], hi = (double)box_hi[3 * c + a];
+                double g = lo - qh[a] > ql[a] - hi ? lo - qh[a] : ql[a] - hi;
+                g = g > 0.0 ? g : 0.0;
+                gap2 += g * g;
+            }
+            if (gap2 * (1.0 - 1e-12) > worst) continue;
+            const i64 lo_r = c * 256, hi_r = lo_r + 256 < n ? lo_r + 256 : n;
+            knn_scan<K>(xyz, ids, lo_r, hi_r, qx, qy, qz, bd, bi);
         }
     }
+    if (!live) return;
 #pragma unroll
     for (int t = 0; t < K; ++t)
         if (t < k) neighbors[(size_t)q * k + t] = (i64)bi[t];
@@ -132,52 +152,18 @@ using namespace mvf;
 
 static inline int knn_width(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 24 ? 24 : k <= 32 ? 32 : k <= 48 ? 48 : 64; }
 
-// Slices of the candidate range: enough blocks for about eight waves per SIMD,
-// at least 4096 candidates per slice.
-static int knn_slices(i64 n)
-{
-    const i64 blocks = (n + 255) / 256;
-    i64 s = (512 + blocks - 1) / blocks;
-    const i64 most = (n + 4095) / 4096;
-    if (s > most) s = most;
-    if (s > 64) s = 64;
-    return (int)(s < 1 ? 1 : s);
-}
-
-extern "C" size_t mvf_knn_workspace_bytes(int64_t n, int32_t k)
-{
-    const int slices = knn_slices(n);
-    if (slices == 1) return 256;
-    const size_t e = (size_t)n * slices * knn_width(k);
-    return align_up(e * sizeof(double)) + align_up(e * sizeof(int));
-}
-
-extern "C" int mvf_knn(const float *xyz, int64_t n, int32_t k, int64_t *neighbors, void *workspace,
-                       size_t workspace_bytes, void *stream)
+extern "C" int mvf_knn(const float *xyz, const int64_t *ids, int64_t n, int32_t k,
+                       const float *box_lo, const float *box_hi, int64_t *neighbors, void *stream)
 {
     MVF_REQUIRE(n >= 1 && n < (1ll << 31) && k >= 1 && k <= 64 && k <= n,
                 "knn: need 1 <= k <= min(64, n), got n=%lld k=%d", (long long)n, k);
     MVF_REQUIRE(xyz && neighbors, "knn: null pointer");
-    const int slices = knn_slices(n), K = knn_width(k);
-    const i64 slice_len = (n + slices - 1) / slices;
-    Arena ar(workspace, workspace_bytes);
-    double *pd = nullptr;
-    int *pi = nullptr;
-    if (slices > 1) {
-        pd = ar.take<double>((size_t)n * slices * K);
-        pi = ar.take<int>((size_t)n * slices * K);
-        if (!ar.ok()) { set_error("knn: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
-    }
-    dim3 grid(cdiv(n, 256), slices), block(256), mgrid(cdiv(n, 256));
+    MVF_REQUIRE((box_lo == nullptr) == (box_hi == nullptr), "knn: box_lo and box_hi go together");
+    const int K = knn_width(k);
+    dim3 grid(cdiv(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define MVF_KNN(K_)                                                                                  \
-    do {                                                                                             \
-        hipLaunchKernelGGL((knn_kernel<K_>), grid, block, 0, st, xyz, (i64)n, k, slice_len, pd, pi,   \
-                           (i64 *)neighbors);                                                        \
-        if (slices > 1)                                                                              \
-            hipLaunchKernelGGL((knn_merge_kernel<K_>), mgrid, block, 0, st, pd, pi, (i64)n, k, slices, \
-                               (i64 *)neighbors);                                                    \
-    } while (0)
+#define MVF_KNN(K_) hipLaunchKernelGGL((knn_kernel<K_>), grid, block, 0, st, xyz, (const i64 *)ids, (i64)n, k, \
+                                       box_lo, box_hi, (i64 *)neighbors)
     if (K == 8) MVF_KNN(8); else if (K == 16) MVF_KNN(16); else if (K == 24) MVF_KNN(24);
     else if (K == 32) MVF_KNN(32); else if (K == 48) MVF_KNN(48); else MVF_KNN(64);
 #undef MVF_KNN

@@ -83,8 +83,7 @@ _SIGNATURES = {
     "mvf_segment_csr": (C.c_int, [_P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_csr_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_softmax_csr_backward": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P]),
-    "mvf_knn_workspace_bytes": (_SZ, [_I64, _I32]),
-    "mvf_knn": (C.c_int, [_P, _I64, _I32, _P, _P, _SZ, _P]),
+    "mvf_knn": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "mvf_mapping_occlusion": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _I64, _P, _I32, _P]),
     "mvf_gather_csr": (C.c_int, [_P, _I32, _P, _I64, _I64, _P, _P]),
     "mvf_segment_softmax_csr": (C.c_int, [_P, _I32, _P, _I64, _F, _I32, _P, _P]),

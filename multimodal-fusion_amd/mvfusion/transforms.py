@@ -510,19 +510,45 @@ class MapImages(ImageTransform):
         return mappings, seen
 
 
+def _morton_order(pos):
+    """Permutation that sorts the points along a Z-order curve (10 bits per
+    axis of the bounding cube)."""
+    lo = pos.min(dim=0).values
+    ext = (pos.max(dim=0).values - lo).max().clamp(min=1e-20)
+    cell = ((pos - lo) / ext * 1023.0).long().clamp_(0, 1023)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    key = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
+    return torch.argsort(key)
+
+
 def knn(xyz, k):
     """Indices [N, k] of the k nearest neighbours of every point among the
     points themselves (the point first), ascending in distance; exact
-    (float64 distances, equal distances by ascending index)."""
+    (float64 distances, equal distances by ascending index).  The kernel gets
+    the points in Z-order (it is several times faster on spatially coherent
+    rows); the result does not depend on that order."""
     device = L.require_device(xyz)
-    pos = xyz.to(device=device, dtype=torch.float32).contiguous()
+    pos = xyz.to(device=device, dtype=torch.float32)
     n = pos.shape[0]
-    out = torch.empty((n, k), dtype=torch.int64, device=device)
-    lib = L.load()
-    ws = L.workspace(lib.mvf_knn_workspace_bytes(n, int(k)), device)
+    perm = _morton_order(pos)
+    pos_s = pos[perm].contiguous()
+    nbr_s = torch.empty((n, k), dtype=torch.int64, device=device)
+    # bounding boxes of the chunks of 256 rows (the last one padded with its own rows)
+    pad = (-n) % 256
+    rows = torch.cat([pos_s, pos_s[-1:].expand(pad, 3)]) if pad else pos_s
+    rows = rows.view(-1, 256, 3)
+    box_lo, box_hi = rows.amin(dim=1).contiguous(), rows.amax(dim=1).contiguous()
     with torch.cuda.device(device):
-        L.check(lib.mvf_knn(L.ptr(pos), n, int(k), L.ptr(out), L.ptr(ws), ws.numel(),
-                            L.stream_ptr(device)))
+        L.check(L.load().mvf_knn(L.ptr(pos_s), L.ptr(perm), n, int(k), L.ptr(box_lo),
+                                 L.ptr(box_hi), L.ptr(nbr_s), L.stream_ptr(device)))
+    out = torch.empty_like(nbr_s)
+    out[perm] = nbr_s
     return out
 
 
