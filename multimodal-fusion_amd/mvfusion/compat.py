@@ -23,7 +23,11 @@ ALIASES = {
 # names the reference imports from modules we only partly replace
 PARTIAL = {
     "torch_points3d.core.multimodal.image": ("mvfusion.mapping", ["ImageMapping", "ImageMappingBatch"]),
-    "torch_points3d.core.data_transform.multimodal.image": ("mvfusion.transforms", ["MapImages", "ImageTransform"]),
+    "torch_points3d.core.data_transform.multimodal.image": (
+        "mvfusion.transforms",
+        ["MapImages", "ImageTransform", "NeighborhoodBasedMappingFeatures",
+         "SelectMappingFromPointId", "DropImagesOutsideDataBoundingBox", "PickKImages",
+         "PickImagesFromMappingArea"]),
     "torch_points3d.utils.multimodal": ("mvfusion.mapping", ["lexargsort", "lexargunique", "lexunique"]),
 }
 
