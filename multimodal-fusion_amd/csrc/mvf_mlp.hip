@@ -69,7 +69,21 @@ struct MlpArgs {
     int dot_ldq;
     float dot_div;
     float *dot_out;
+    // pool epilogue (pool_out != null; POOL kernels): the last layer's output y is not stored;
+    // pool_out[s][c] = (sum over the rows r of segment s, in order, of y[r][c] * pool_att[r])
+    //                  * pool_gate[s]     (no gate factor when pool_gate == null)
+    // with s = dot_seg[r]; rows are grouped by segment, segments ascending.
+    const float *pool_att;
+    const float *pool_gate;
+    float *pool_out;
 };
+
+// Rows of one staging step of the pool epilogue and the LDS pitch of a staged row.
+constexpr int POOL_STAGE_ROWS = 16;
+constexpr int POOL_PITCH = MLP_MAX_C + 4;
+// Segments are folded inside tiles of this many rows (one wave's rows); a segment that
+// crosses a tile boundary is completed with atomic adds and must start from zero.
+constexpr int POOL_TILE = 32;
 
 __host__ __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
 // LDS rows of a layer's transposed weights
@@ -251,7 +265,7 @@ __device__ __forceinline__ void mlp_store(
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
 // and LDS offsets become immediates.  NL < 0 is the general kernel that takes
 // everything from the arguments.
-template <int NL, int WMASK>
+template <int NL, int WMASK, bool POOL = false>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 {
     constexpr bool FIXED = NL >= 0;
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
     // transposed weights [k][cout_pad] of the layers, as offsets into smem (plain
     // offsets keep the accesses LDS instructions)
     int woff[MLP_MAX_LAYERS];
+    int stage_off;                                      // POOL: staging rows of the waves, behind the weights
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jrow = lane & 31, kh = lane >> 5;
 
@@ -279,6 +294,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             woff[l] = w;
             if (l < nlayers) w += mlp_wrows(l, A.L[l].cin) * cop_of(l);
         }
+        stage_off = w;
     }
     // channel scale / shift: y = (x W^T + bias - mean) / sqrt(var + eps) * gamma + beta
     for (int idx = tid; idx < nlayers * MLP_MAX_C; idx += MLP_THREADS) {
@@ -342,6 +358,17 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         // layer, so that neither load is waited for at the end of the tile
         const int qseg = (A.dot_out && live) ? A.dot_seg[row] : 0;
         float qv[16];
+        // pool epilogue: the row's segment and attention weight now, the segment's gate
+        // after the first layer; the segments of the rows next to the wave's tile tell
+        // whether its first / last segment continues in a neighbouring tile
+        int pseg = -1, pprev = -1, pnext = -1;
+        float patt = 0.f, pgate = 1.f;
+        if (POOL) {
+            const i64 t0 = base + wave * 32;
+            if (live) { pseg = A.dot_seg[row]; patt = A.pool_att[row]; }
+            if (t0 > 0 && t0 < A.rows) pprev = A.dot_seg[t0 - 1];
+            if (t0 + POOL_TILE < A.rows) pnext = A.dot_seg[t0 + POOL_TILE];
+        }
 
         // ---- first layer: the lane's half of each 64-column chunk of its row ----
         for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -402,6 +429,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             }
             if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
+        if (POOL && A.pool_gate && live) pgate = A.pool_gate[pseg];
         if (A.dot_out) {
             const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
             const int cq = A.L[nlayers - 1].cout;
@@ -438,7 +466,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                     if ((step + 1) % per == 0) {
                         const int g = step / per;
                         mlp_epilogue4(n0, g, L2);
-                        if (live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
+                        if (!POOL && live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
                     }
                 };
                 mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, A.debug);
@@ -446,9 +474,10 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     mlp_epilogue4(n1, g, L2);
-                    if (live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
+                    if (!POOL && live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
                 }
                 acc0 = n0; acc1 = n1;
+                if (POOL) goto pool_tail;
                 goto tile_done;
             }
             mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, A.debug);
@@ -480,15 +509,81 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mlp_epilogue4(acc0, g, L);
-                if (live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
+                if (!POOL && live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
             }
             if (wide) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     mlp_epilogue4(acc1, g, L);
-                    if (live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
+                    if (!POOL && live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
                 }
             }
+        }
+    pool_tail:
+        if (POOL) {
+            // Attention-weighted segment sum of the finished rows (pooling.py:519-530).
+            // The wave's 32 rows go through LDS 16 at a time: a lane writes the 32 / 64
+            // channels of its row (times the row's attention weight), then lane c folds
+            // channel c over the staged rows in row order.  The segment of a row is
+            // wave-uniform (read from the row's lane), so segment changes are scalar
+            // branches.  A segment that lies inside the tile is stored; one that
+            // continues in a neighbouring tile is added atomically to its zeroed row.
+            const bool wide = cop_of(nlayers - 1) > 32;
+            const int cout = A.L[nlayers - 1].cout;
+            float *stg = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
+            int cur = __builtin_amdgcn_readlane(pseg, 0);
+            bool partial = cur == pprev;                 // the current segment began before this tile
+            float accv = 0.f;
+            auto flush = [&](int seg, float v, bool part, float gate_) {
+                if (seg < 0 || lane >= cout) return;
+                if (A.pool_gate) v = __fmul_rn(v, gate_);
+                float *o = A.pool_out + (size_t)seg * cout + lane;
+                if (part) unsafeAtomicAdd(o, v);
+                else *o = v;
+            };
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if ((jrow >> 4) == half) {
+                    float *p = stg + (jrow & 15) * POOL_PITCH + 4 * kh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *(float4 *)(p + 8 * g) = make_float4(
+                            __fmul_rn(acc0[4 * g], patt), __fmul_rn(acc0[4 * g + 1], patt),
+                            __fmul_rn(acc0[4 * g + 2], patt), __fmul_rn(acc0[4 * g + 3], patt));
+                    if (wide) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *(float4 *)(p + 32 + 8 * g) = make_float4(
+                                __fmul_rn(acc1[4 * g], patt), __fmul_rn(acc1[4 * g + 1], patt),
+                                __fmul_rn(acc1[4 * g + 2], patt), __fmul_rn(acc1[4 * g + 3], patt));
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float v[POOL_STAGE_ROWS];
+#pragma unroll
+                for (int i = 0; i < POOL_STAGE_ROWS; ++i) v[i] = stg[i * POOL_PITCH + lane];
+#pragma unroll
+                for (int i = 0; i < POOL_STAGE_ROWS; ++i) {
+                    const int r = half * POOL_STAGE_ROWS + i;
+                    const int s = __builtin_amdgcn_readlane(pseg, r);
+                    if (s != cur) {
+                        // r >= 1 here: row 0 defines cur
+                        flush(cur, accv, partial, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pgate), r > 0 ? r - 1 : 0)));
+                        partial = false;
+                        cur = s;
+                        accv = 0.f;
+                    }
+                    accv = __fadd_rn(accv, v[i]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // rows past the end carry segment -1: a tile that holds some has flushed its
+            // last segment at the change and ends with cur = -1
+            flush(cur, accv, partial || cur == pnext, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pgate), 31)));
         }
     tile_done:;
     }
@@ -542,13 +637,20 @@ __global__ __launch_bounds__(256) void attention_comp_kernel(
 __global__ __launch_bounds__(256) void attention_scores_kernel(
     const i64 *__restrict__ ptr, i64 nseg, int G, int group_scaling,
     float eps, const float *__restrict__ gate_w, const float *__restrict__ gate_b,
-    const float *__restrict__ comp, float *__restrict__ att, float *__restrict__ gate)
+    const float *__restrict__ comp, float *__restrict__ att, float *__restrict__ gate,
+    float *__restrict__ pool_out, int pool_C)
 {
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= nseg * G) return;
     const i64 s = t / G;
     const int g = (int)(t - s * G);
     const i64 a = ptr[s], b = ptr[s + 1];
+    // Ahead of the pool epilogue of the layer chain (G == 1): the rows of empty segments
+    // and of segments that cross a tile boundary start from zero.
+    if (pool_out && (b <= a || a / POOL_TILE != (b - 1) / POOL_TILE)) {
+        float *o = pool_out + (size_t)s * pool_C;
+        for (int c = 0; c < pool_C; ++c) o[c] = 0.f;
+    }
     float mx = 0.f;                                    // segment max of nothing is 0
     for (i64 r = a; r < b; ++r) {
         const float c = comp[(size_t)r * G + g];
@@ -721,13 +823,18 @@ static int mlp_forward_impl(
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
-    float dot_div, float *dot_out, void *stream)
+    float dot_div, float *dot_out, void *stream,
+    const float *pool_att = nullptr, const float *pool_gate = nullptr, float *pool_out = nullptr)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
     MVF_REQUIRE(mode >= 0 && mode <= 2, "mlp_forward: unknown input mode %d", mode);
     if (rows == 0) return MVF_OK;
-    MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out), "mlp_forward: bad first input");
+    MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out || pool_out), "mlp_forward: bad first input");
+    if (pool_out) {
+        MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
+        out = pool_out; ldo = layers[nlayers - 1].cout;                 // never written through `out`
+    }
     if (dot_out) {
         MVF_REQUIRE(dot_q && dot_seg && layers[nlayers - 1].cout <= 32 && dot_ldq >= layers[nlayers - 1].cout,
                     "mlp_forward_dot: needs query rows, the row -> query map and at most 32 output channels");
@@ -761,6 +868,8 @@ static int mlp_forward_impl(
     A.out = out;
     A.ldo = ldo;
     A.dot_q = dot_q; A.dot_seg = dot_seg; A.dot_ldq = dot_ldq; A.dot_div = dot_div; A.dot_out = dot_out;
+    A.pool_att = pool_att; A.pool_gate = pool_gate; A.pool_out = pool_out;
+    if (pool_out) A.dot_seg = dot_seg;
     A.debug = 0;
 #ifdef MVF_MLP_DEBUG
     A.debug = g_mlp_debug;
@@ -769,8 +878,9 @@ static int mlp_forward_impl(
     const bool al_a = ((uintptr_t)xa % 16 == 0) && lda % 4 == 0;
     const bool al_b = !xb || (((uintptr_t)xb % 16 == 0) && ldb % 4 == 0);
     A.vec_in = al_a && al_b && cin0 % 8 == 0 && cols_a % 4 == 0;
-    A.vec_out = dot_out || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
-    const size_t lds = mlp_lds_bytes(layers, nlayers);
+    A.vec_out = dot_out || pool_out || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
+    const size_t lds = mlp_lds_bytes(layers, nlayers) +
+                       (pool_out ? sizeof(float) * MLP_WAVES * POOL_STAGE_ROWS * POOL_PITCH : 0);
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -796,7 +906,18 @@ static int mlp_forward_impl(
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_>), grid, dim3(MLP_THREADS), lds, st, A);   \
     } while (0)
-    if (!fixed) MVF_MLP_LAUNCH(-1, 0);
+#define MVF_MLP_LAUNCH_POOL(NL_, WM_)                                                            \
+    do {                                                                                         \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, true>,              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, true>), grid, dim3(MLP_THREADS), lds, st, A); \
+    } while (0)
+    if (pool_out) {
+        MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
+                    "mlp_forward_pool: two layers of equal output width on 16-byte aligned, unsummed inputs only");
+        if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0);
+        else MVF_MLP_LAUNCH_POOL(2, 3);
+    } else if (!fixed) MVF_MLP_LAUNCH(-1, 0);
     else switch (nlayers * 8 + wmask) {
     case 8 + 0: MVF_MLP_LAUNCH(1, 0); break;
     case 8 + 1: MVF_MLP_LAUNCH(1, 1); break;
@@ -814,6 +935,7 @@ static int mlp_forward_impl(
     default: MVF_MLP_LAUNCH(3, 7); break;
     }
 #undef MVF_MLP_LAUNCH
+#undef MVF_MLP_LAUNCH_POOL
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -840,6 +962,17 @@ extern "C" int mvf_mlp_forward_dot(
                             nlayers, nullptr, 0, queries, ldq, row2seg, divisor, dot_out, stream);
 }
 
+extern "C" int mvf_mlp_forward_pool(
+    const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
+    const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
+    int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
+    const float *att, const int32_t *row2seg, const float *gate, float *pool_out, void *stream)
+{
+    MVF_REQUIRE(pool_out, "mlp_forward_pool: null output");
+    return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
+                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, gate, pool_out);
+}
+
 extern "C" int mvf_attention_pool(
     const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
     const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G,
@@ -853,7 +986,10 @@ extern "C" int mvf_attention_pool(
                 "attention_pool: bad key / query layout");
     MVF_REQUIRE(!gating || gate, "attention_pool: gating needs the gate buffer");
     if (nseg == 0) return MVF_OK;
-    MVF_REQUIRE(ptr && out && (rows == 0 || (x_mod && comp && att)), "attention_pool: null buffer");
+    MVF_REQUIRE(ptr && out && (rows == 0 || (comp && att)), "attention_pool: null buffer");
+    // x_mod == NULL: scores only; `out` is prepared for mvf_mlp_forward_pool
+    const bool prepare = x_mod == nullptr && rows > 0;
+    MVF_REQUIRE(!prepare || G == 1, "attention_pool: the fused pool handles one group");
     hipStream_t st = (hipStream_t)stream;
     if (keys && rows > 0) {
         const float dim_div = dim_scaling ? (float)sqrt((double)D) : 0.f;
@@ -862,7 +998,12 @@ extern "C" int mvf_attention_pool(
     }
     hipLaunchKernelGGL(attention_scores_kernel, dim3(cdiv(nseg * G, 256)), dim3(256), 0, st,
                        (const i64 *)ptr, (i64)nseg, G, group_scaling, eps, gate_w, gate_b,
-                       (const float *)comp, att, gating ? gate : (float *)nullptr);
+                       (const float *)comp, att, gating ? gate : (float *)nullptr,
+                       prepare ? out : (float *)nullptr, C);
+    if (prepare) {
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     // 16-byte vectors when no vector of 4 channels straddles two groups
     const bool vec4 = C % 4 == 0 && ((uintptr_t)x_mod % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                       (G == 1 || (C % G == 0 && (C / G) % 4 == 0));

@@ -27,7 +27,8 @@ PARTIAL = {
         "mvfusion.transforms",
         ["MapImages", "ImageTransform", "NeighborhoodBasedMappingFeatures",
          "SelectMappingFromPointId", "DropImagesOutsideDataBoundingBox", "PickKImages",
-         "PickImagesFromMappingArea"]),
+         "PickImagesFromMappingArea", "PickMappingsFromMappingFeatures", "JitterMappingFeatures",
+         "CropImageGroups"]),
     "torch_points3d.utils.multimodal": ("mvfusion.mapping", ["lexargsort", "lexargunique", "lexunique"]),
 }
 

@@ -86,11 +86,13 @@ def _check_eval(spec):
             "(train-mode batch statistics and backward are not implemented)")
 
 
-def _launch(src, specs, cols, out, ldo_tensor, dot=None):
+def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     """One mvf_mlp_forward launch.  src = (xa, ga, xb, gb, mode); specs = list
     of (LayerSpec, lo, hi); out = tensor view whose first element is the
     output's first column, ldo_tensor = row stride in floats.  dot = (queries,
-    row2seg, divisor): mvf_mlp_forward_dot, `out` is the [rows] dot output."""
+    row2seg, divisor): mvf_mlp_forward_dot, `out` is the [rows] dot output.
+    pool = (att, row2seg, gate): mvf_mlp_forward_pool, `out` is the prepared
+    [nseg, cout] pool output."""
     lib = L.load()
     xa, ga, xb, gb, mode = src
     keep = []
@@ -111,7 +113,14 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None):
     rows = xa.shape[0] if ga is None else ga.shape[0]
     dev = xa.device
     with torch.cuda.device(dev):
-        if dot is None:
+        if pool is not None:
+            att, seg, gate = pool
+            L.check(lib.mvf_mlp_forward_pool(
+                L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
+                L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
+                L.ptr(gb), rows, arr, len(specs), L.ptr(att), L.ptr(seg), L.ptr(gate),
+                L.ptr(out), L.stream_ptr(dev)))
+        elif dot is None:
             L.check(lib.mvf_mlp_forward(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
                 L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
@@ -199,6 +208,25 @@ def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0, dot=Non
     return x
 
 
+def pool_fusable(specs, x, num_groups):
+    """Can pooled_layers() run these layers with the attention-weighted segment
+    sum as their epilogue?  Two layers of one output width <= 64 (a multiple of
+    4) on an aligned float32 input, one attention group."""
+    return (num_groups == 1 and len(specs) == 2 and specs[0].cout == specs[1].cout
+            and specs[1].cout <= _MAX_C and specs[1].cout % 4 == 0
+            and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+            and x.shape[1] % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and x.shape[0] > 0)
+
+
+def pooled_layers(specs, x, att, row2seg, gate, out):
+    """out[s] = (sum_{r in s} specs(x)[r] * att[r]) * gate[s]: the layer chain with
+    the pool epilogue (needs pool_fusable; `out` prepared by attention_pool(None, ...))."""
+    _launch((x.detach(), None, None, None, 0), [(sp, 0, sp.cout) for sp in specs], None, out,
+            specs[-1].cout, pool=(att, row2seg, gate))
+    return out
+
+
 def csr_row_segments(ptr, rows):
     """int32 [rows]: segment index of every row of a CSR pointer array."""
     lib = L.load()
@@ -215,10 +243,17 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
                    group_scaling=False, gate_w=None, gate_b=None, gating=False, eps=1e-12):
     """Returns (x_pool, comp, att, gate).  Either ``keys``/``queries`` or
     ``comp`` (the compatibilities) is given; ``row2seg`` maps key rows to query
-    rows (None: one query row per key row)."""
+    rows (None: one query row per key row).  ``x_mod`` may be the number of
+    value channels instead of the values (one group only): the scores are
+    computed and x_pool comes back prepared for pooled_layers()."""
     lib = L.load()
-    dev = x_mod.device
-    rows, Cm = x_mod.shape
+    if isinstance(x_mod, int):
+        src = keys if keys is not None else comp
+        dev, rows, Cm, x_mod = src.device, src.shape[0], x_mod, None
+    else:
+        dev = x_mod.device
+        rows, Cm = x_mod.shape
+        x_mod = x_mod.detach().contiguous()
     nseg = ptr.shape[0] - 1
     G = int(num_groups)
     if keys is None:
@@ -230,7 +265,6 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
     out = torch.empty((nseg, Cm), dtype=torch.float32, device=dev)
     f = lambda t: None if t is None else t.detach().float().contiguous().view(-1)
     gw, gb = f(gate_w), f(gate_b)
-    x_mod = x_mod.detach().contiguous()
     if nseg > 0:
         with torch.cuda.device(dev):
             L.check(lib.mvf_attention_pool(

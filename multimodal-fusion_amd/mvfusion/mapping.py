@@ -359,6 +359,24 @@ class ImageMapping(CSRData):
         return ImageMappingBatch
 
     @property
+    def bounding_boxes(self):
+        """(w_min, w_max, h_min, h_max) of the mapped pixels of every image, one
+        entry per image id up to the largest one present; an id without
+        mappings gets zeros (core/multimodal/image.py:1869-1879, whose
+        torch_scatter reductions size their output by the largest index and fill
+        empty slots with 0)."""
+        sizes = self.values[1].pointers[1:] - self.values[1].pointers[:-1]
+        image_ids = self.images.repeat_interleave(sizes)
+        n_img = int(image_ids.max()) + 1 if image_ids.numel() else 0
+        pix = self.pixels
+        idx2 = image_ids[:, None].expand(-1, 2)
+        lo = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
+            0, idx2, pix, 'amin', include_self=False)
+        hi = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
+            0, idx2, pix, 'amax', include_self=False)
+        return lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1]
+
+    @property
     def feature_map_indexing(self):
         """Index tuple for ``X[idx]`` on ``X`` of shape [B, C, H, W]
         (core/multimodal/image.py:1881-1895)."""

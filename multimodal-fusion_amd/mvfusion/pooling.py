@@ -685,7 +685,11 @@ class GroupBimodalCSRPool(_AttentivePool):
         ptr = _device_ptr(x_mod, csr_idx)
         row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
         score = [_dense.linear_layer(self.E_score)]
-        x_mod = _dense.run_layers(_dense.mlp_layers(self.E_mod), x_mod)
+        e_mod = _dense.mlp_layers(self.E_mod)
+        fuse_pool = (not (self.save_last or self.use_mod)
+                     and _dense.pool_fusable(e_mod, x_mod, self.num_groups))
+        if not fuse_pool:
+            x_mod = _dense.run_layers(e_mod, x_mod)
         if self.use_mod or self.save_last:
             x_map = self.E_map.embed(x_map, ptr, row2seg)
             if self.use_mod:
@@ -695,10 +699,13 @@ class GroupBimodalCSRPool(_AttentivePool):
         else:
             comp = self.E_map.embed(x_map, ptr, row2seg, tail=score)
         x_pool, comp, att, gate = _dense.attention_pool(
-            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), comp=comp,
+            self.out_mod if fuse_pool else x_mod, ptr, self.num_groups,
+            self._chan2group(x_mod.device), comp=comp,
             group_scaling=self.group_scaling,
             gate_w=None if self.G is None else self.G.weight,
             gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
+        if fuse_pool:
+            _dense.pooled_layers(e_mod, x_mod, att, row2seg, gate, x_pool)
         if self.save_last:
             self._last_x_map = x_map
             self._last_x_mod = x_mod
@@ -785,8 +792,14 @@ class QKVBimodalCSRPool(_AttentivePool):
         row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
         k_lin, q_lin = [_dense.linear_layer(self.K)], [_dense.linear_layer(self.Q)]
 
-        # values : V x F_mod
-        x_mod = _dense.run_layers(_dense.mlp_layers(self.E_mod), x_mod)
+        # values : V x F_mod.  Unless the encoded values are asked for (save_last,
+        # mixed keys / queries) they are produced last, inside the launch that sums
+        # them per point (_dense.pooled_layers).
+        e_mod = _dense.mlp_layers(self.E_mod)
+        fuse_pool = (not (self.save_last or self.use_mod_q or self.use_mod_k)
+                     and _dense.pool_fusable(e_mod, x_mod, self.num_groups))
+        if not fuse_pool:
+            x_mod = _dense.run_layers(e_mod, x_mod)
 
         # queries : N x (D x num_groups), or V x ... when the modality is mixed in
         if self.use_mod_q:
@@ -813,11 +826,14 @@ class QKVBimodalCSRPool(_AttentivePool):
             keys = self.E_map.embed(x_map, ptr, row2seg, tail=k_lin)
 
         x_pool, comp, att, gate = _dense.attention_pool(
-            x_mod, ptr, self.num_groups, self._chan2group(x_mod.device), keys=keys, comp=comp,
+            self.out_mod if fuse_pool else x_mod, ptr, self.num_groups,
+            self._chan2group(x_mod.device), keys=keys, comp=comp,
             queries=queries, row2seg=None if self.use_mod_q else row2seg, nc_qk=self.nc_qk,
             dim_scaling=self.dim_scaling, group_scaling=self.group_scaling,
             gate_w=None if self.G is None else self.G.weight,
             gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
+        if fuse_pool:
+            _dense.pooled_layers(e_mod, x_mod, att, row2seg, gate, x_pool)
 
         if self.save_last:
             self._last_x_map = x_map

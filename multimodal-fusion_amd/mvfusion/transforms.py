@@ -716,3 +716,121 @@ class PickImagesFromMappingArea(ImageTransform):
         if idx.shape[0] == 0 and images.num_views > 0 and self.n_min > 0:
             idx = idx[:self.n_min]
         return data, images[idx]
+
+
+class PickMappingsFromMappingFeatures(ImageTransform):
+    """Drops the views whose mapping features fall outside per-feature lower /
+    upper bounds, both exclusive (core/data_transform/multimodal/image.py:877-931)."""
+
+    def __init__(self, feat=None, lower=None, upper=None):
+        self.feat = self.sanitize(feat)
+        self.lower = self.sanitize(lower)
+        self.upper = self.sanitize(upper)
+        if len(self.lower) == 0:
+            self.lower = [None] * len(self.feat)
+        if len(self.upper) == 0:
+            self.upper = [None] * len(self.feat)
+        for x in [self.lower, self.upper]:
+            assert len(x) == len(self.feat), \
+                f"{x} has {len(x)} elements but {len(self.feat)} were expected."
+
+    @staticmethod
+    def sanitize(x):
+        if x is None:
+            return []
+        if isinstance(x, (str, bytes)) or not hasattr(x, '__iter__'):
+            return [x]
+        return x
+
+    def _process(self, data, images):
+        m = images.mappings
+        if m is None or not m.has_features or len(self.feat) == 0:
+            return data, images
+        assert max(self.feat) == 0 or max(self.feat) < m.features.shape[1], \
+            f"Out of bounds feature id {max(self.feat)}."
+        features = m.features.view(m.num_items, -1)
+        view_mask = torch.ones(m.num_items, dtype=torch.bool, device=features.device)
+        for i_feat, lower, upper in zip(self.feat, self.lower, self.upper):
+            if lower is not None:
+                view_mask = view_mask & (features[:, i_feat] > lower)
+            if upper is not None:
+                view_mask = view_mask & (features[:, i_feat] < upper)
+        return data, images.select_views(view_mask)
+
+
+class JitterMappingFeatures(ImageTransform):
+    """Adds clamped gaussian noise to the mapping features
+    (core/data_transform/multimodal/image.py:934-959)."""
+
+    def __init__(self, sigma=0.02, clip=0.03):
+        self.sigma = sigma
+        self.clip = clip
+
+    def _process(self, data, images):
+        m = images.mappings
+        if m is None or not m.has_features:
+            return data, images
+        noise = self.sigma * torch.randn(m.features.shape)
+        noise = noise.clamp(-self.clip, self.clip)
+        m.features = m.features + noise.to(m.features.device)
+        return data, images
+
+
+class CropImageGroups(ImageTransform):
+    """Greedy cropping of the images around their mappings: every image goes to
+    the smallest size of the family (min_size, min_size), (2 min_size, min_size),
+    (2 min_size, 2 min_size), ... , img_size that holds the padded bounding box of
+    its mapped pixels, the box is centred in the crop as far as the image
+    borders allow, and the images of one size come back as one
+    SameSettingImageData of an ImageData
+    (core/data_transform/multimodal/image.py:1040-1141)."""
+
+    def __init__(self, padding=0, min_size=64):
+        assert padding >= 0, f"Expected a positive scalar but got {padding} instead."
+        assert ((min_size & (min_size - 1)) == 0) & (min_size != 0), \
+            f"Expected a power of two but got {min_size} instead."
+        self.padding = padding
+        self.min_size = min_size
+
+    def _process(self, data, images):
+        from .images import ImageData
+        assert images.mappings is not None, "No mappings found in images."
+        if images.num_views == 0:
+            return data, ImageData([images])
+        img_size = tuple(images.img_size)
+        w_min, w_max, h_min, h_max = images.mappings.bounding_boxes
+        w_min = torch.clamp(w_min - self.padding, 0)
+        h_min = torch.clamp(h_min - self.padding, 0)
+        w_max = torch.clamp(w_max + self.padding, 0, img_size[0])
+        h_max = torch.clamp(h_max + self.padding, 0, img_size[1])
+        widths, heights = w_max - w_min, h_max - h_min
+
+        families = {}
+        size = (self.min_size, self.min_size)
+        step = 0
+        image_ids = torch.arange(images.num_views, device=widths.device)
+        while all(a <= b for a, b in zip(size, img_size)) and image_ids.shape[0] > 0:
+            if size == img_size:
+                families[size] = image_ids
+                image_ids = image_ids[:0]
+                break
+            fits = torch.logical_and(widths[image_ids] <= size[0], heights[image_ids] <= size[1])
+            if bool(fits.any()):
+                families[size] = image_ids[fits]
+            image_ids = image_ids[~fits]
+            # widths double on even steps, heights on odd ones
+            size = (min(size[0] * 2 ** ((step + 1) % 2), img_size[0]),
+                    min(size[1] * 2 ** (step % 2), img_size[1]))
+            step += 1
+        if img_size not in families and image_ids.shape[0] > 0:
+            families[img_size] = image_ids
+
+        out = []
+        for size, idx in families.items():
+            off_x = torch.clamp((w_min[idx] - (size[0] - widths[idx]) / 2.).long(),
+                                0, img_size[0] - size[0])
+            off_y = torch.clamp((h_min[idx] - (size[1] - heights[idx]) / 2.).long(),
+                                0, img_size[1] - size[1])
+            offsets = torch.stack((off_x, off_y), dim=1).long()
+            out.append(images[idx].update_cropping(size, offsets))
+        return data, ImageData(out)

@@ -821,6 +821,64 @@ def gen_cropping():
     save("cropping", **arrs)
 
 
+def gen_crop_groups():
+    """CropImageGroups (with ImageMapping.bounding_boxes underneath) and
+    PickMappingsFromMappingFeatures
+    (core/data_transform/multimodal/image.py:877-931, 1040-1141) on one sample
+    whose images' mappings span boxes of very different sizes."""
+    image, tr = ref["image"], ref["transforms"]
+    rng = np.random.default_rng(91)
+    n, n_img, W, H = 500, 7, 256, 192
+    # per image: a box the mapped pixels are drawn from (every image is seen: the
+    # reference's crop asserts one offset per image present in the mappings)
+    boxes = [(10, 40, 20, 50), (0, 256, 0, 192), (100, 200, 60, 130), (200, 256, 150, 192),
+             (30, 150, 5, 60), (250, 256, 0, 10), (0, 70, 0, 192)]
+    pid, iid, pix = [], [], []
+    for i, b in enumerate(boxes):
+        if b is None:
+            continue
+        pts = np.sort(rng.permutation(n)[:rng.integers(20, 120)])
+        pid.append(pts)
+        iid.append(np.full(pts.shape[0], i))
+        pix.append(np.stack([rng.integers(b[0], b[1], pts.shape[0]),
+                             rng.integers(b[2], b[3], pts.shape[0])], 1))
+    pid, iid = np.concatenate(pid).astype(np.int64), np.concatenate(iid).astype(np.int64)
+    pix = np.concatenate(pix).astype(np.int16)
+    feat = rng.random((pid.shape[0], 3)).astype(np.float32)
+    # feature maps whose values name their own position (exact in float32), so that
+    # the fixture only keeps the shape and the sum of every cropped map
+    x = np.arange(n_img * 2 * H * W, dtype=np.float32).reshape(n_img, 2, H, W)
+    pos_img = rng.random((n_img, 3))
+
+    def fresh():
+        m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n)
+        return image.SameSettingImageData(
+            path=np.array([f"v{i}" for i in range(n_img)], dtype='O'), pos=T(pos_img),
+            ref_size=(W, H), proj_upscale=1, downscale=1, mappings=m, x=T(x))
+
+    base = fresh()
+    arrs = dict(pos_img=pos_img, size=np.array([W, H]), n_img=n_img)
+    arrs.update(mapping_arrays(base.mappings, "in_"))
+    for k, v in zip(("w_min", "w_max", "h_min", "h_max"), base.mappings.bounding_boxes):
+        arrs["bbox_" + k] = v.numpy()
+    data = _refshim.Data(pos=T(rng.random((n, 3)).astype(np.float32)))
+    for tag, kw in (("pad0", dict(padding=0, min_size=32)), ("pad8", dict(padding=8, min_size=64))):
+        _, out = tr.CropImageGroups(**kw)(data, fresh())
+        arrs[tag + "_n"] = len(out)
+        for j, im in enumerate(out):
+            t = f"{tag}_{j}"
+            arrs[t + "_path"] = np.array([str(p) for p in im.path])
+            arrs[t + "_crop_size"] = np.array(im.crop_size)
+            arrs[t + "_crop_offsets"] = im.crop_offsets.numpy()
+            arrs[t + "_x_shape"] = np.array(im.x.shape)
+            arrs[t + "_x_sum"] = im.x.double().sum(dim=(1, 2, 3)).numpy()
+            arrs.update(mapping_arrays(im.mappings, t + "_"))
+    _, out = tr.PickMappingsFromMappingFeatures(feat=[0, 2], lower=[0.2, None], upper=[None, 0.7])(data, fresh())
+    arrs["pmf_path"] = np.array([str(p) for p in out.path])
+    arrs.update(mapping_arrays(out.mappings, "pmf_"))
+    save("crop_groups", **arrs)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -874,6 +932,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping", "crop_groups"]
     for w in which:
         globals()["gen_" + w]()

@@ -219,3 +219,68 @@ def test_mlp_chain_dot_epilogue():
             assert got.shape == (rows, 1)
             err = (got.double() - want).abs().max().item()
             assert err <= 1e-5 * max(want.abs().max().item(), 1e-3), (rows, chans, D, err)
+
+
+@pytest.mark.parametrize("C,gating", [(64, True), (32, True), (48, False), (8, True)])
+def test_mlp_chain_pool_epilogue(C, gating):
+    """The value encoder with the attention-weighted segment sum as epilogue
+    against encoder launch + attention_pool on the same compatibilities:
+    identical bits for every segment inside one 32-row tile, 1e-6 of the output
+    scale for the segments that cross a tile boundary; empty segments, segments of
+    more than 64 rows (three tiles) and a ragged last tile included.  Then the two
+    modules that use it, with and without save_last (which keeps the unfused
+    launches)."""
+    from mvfusion import dense
+    rng = np.random.default_rng(11)
+    N = 30011
+    counts = np.minimum(rng.poisson(4, N), 32)
+    counts[rng.random(N) < 0.05] = 0
+    counts[[17, 5000, N - 1]] = [70, 131, 45]
+    counts[0] = 0
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    Vw = int(ptr[-1])
+    x_mod = T((rng.random((Vw, C)) - 0.3).astype(np.float32))
+    comp = T((rng.random((Vw, 1)) * 2 - 1).astype(np.float32))
+    dptr = T(ptr)
+    torch.manual_seed(C)
+    e_mod = _random_module(pooling.MLP([C, C, C], bias=False), 3).to(DEV).eval()
+    specs = dense.mlp_layers(e_mod)
+    assert dense.pool_fusable(specs, x_mod, 1)
+    kw = dict(comp=comp, group_scaling=True, gating=gating,
+              gate_w=torch.tensor([[1.3]], device=DEV) if gating else None,
+              gate_b=torch.tensor([[0.1]], device=DEV) if gating else None)
+    plain, _, att, gate = dense.attention_pool(dense.run_layers(specs, x_mod), dptr, 1, None, **kw)
+    row2seg = dense.csr_row_segments(dptr, Vw)
+
+    def fused_pass():
+        out, _, att2, gate2 = dense.attention_pool(C, dptr, 1, None, **kw)
+        assert torch.equal(att2, att) and (gate is None or torch.equal(gate2, gate))
+        return dense.pooled_layers(specs, x_mod, att2, row2seg, gate2, out)
+
+    fused, again = fused_pass(), fused_pass()
+    assert fused.shape == plain.shape == (N, C) and float(plain.abs().max()) > 0.01
+    inside = (ptr[:-1] // 32 == (ptr[1:] - 1) // 32) | (counts == 0)
+    two_tiles = (ptr[:-1] // 32 + 1 == (ptr[1:] - 1) // 32)
+    assert inside.sum() > 0.8 * N and (~inside).sum() > 100
+    m = torch.from_numpy(inside).to(DEV)
+    assert torch.equal(fused[m], plain[m])
+    _close(fused, plain.cpu().numpy(), rtol=1e-6)
+    assert float(fused[T(counts == 0)].abs().max()) == 0.0
+    # run to run: only sums of three or more tile partials may change bits
+    m2 = torch.from_numpy(inside | two_tiles).to(DEV)
+    assert torch.equal(fused[m2], again[m2])
+
+    # the modules: save_last keeps the unfused launches (and sums the key / score
+    # layers' inputs in another order, so no bit equality here)
+    x_main = T(rng.random((N, 16)).astype(np.float32))
+    x_map = T(rng.random((Vw, 8)).astype(np.float32))
+    qkv = _random_module(pooling.QKVBimodalCSRPool(
+        in_main=16, in_map=8, in_mod=C, out_mod=C, num_groups=1, nc_qk=8, gating=False), 3).to(DEV).eval()
+    grp = _random_module(pooling.GroupBimodalCSRPool(
+        in_map=8, in_mod=C, num_groups=1, gating=False, group_scaling=True), 4).to(DEV).eval()
+    for mod, args in ((qkv, (x_main, x_mod, x_map, dptr)), (grp, (None, x_mod, x_map, dptr))):
+        a = mod(*args)
+        mod.save_last = True
+        b = mod(*args)
+        assert float(b.abs().max()) > 0.01
+        _close(a, b.cpu().numpy(), rtol=1e-5)

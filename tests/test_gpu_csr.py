@@ -352,3 +352,45 @@ def test_cropping_golden(golden):
             (4, 4), torch.full((n_img, 2), 1000, dtype=torch.int64, device=DEV))
     assert np.array_equal(far.pointers.cpu().numpy(), g["far_pointers"])
     assert np.array_equal(far.pixels.cpu().numpy(), g["far_pixels"])
+
+
+def test_crop_image_groups_golden(golden):
+    """CropImageGroups: size families, centred offsets, cropped maps and rebuilt
+    mappings of every family against the reference's transform."""
+    from mvfusion.images import ImageData, SameSettingImageData
+    from mvfusion.transforms import CropImageGroups
+    g = golden("crop_groups")
+    n_img, (W, H) = int(g["n_img"]), (int(v) for v in g["size"])
+
+    def sample():
+        m = M.ImageMapping.from_csr_arrays(
+            T(g["in_pointers"]), T(g["in_images"]), T(g["in_pixels"]), T(g["in_features"]),
+            view_pointers=T(g["in_view_pointers"]))
+        x = torch.arange(n_img * 2 * H * W, dtype=torch.float32, device=DEV).view(n_img, 2, H, W)
+        return SameSettingImageData(
+            path=[f"v{i}" for i in range(n_img)], pos=T(g["pos_img"]), ref_size=(W, H),
+            proj_upscale=1, downscale=1, mappings=m, x=x)
+
+    class Data:
+        pos = torch.zeros(3, 3)
+
+    for tag, kw in (("pad0", dict(padding=0, min_size=32)), ("pad8", dict(padding=8, min_size=64))):
+        _, out = CropImageGroups(**kw)(Data(), sample())
+        assert isinstance(out, ImageData) and len(out) == int(g[tag + "_n"])
+        for j, im in enumerate(out):
+            t = f"{tag}_{j}"
+            assert [str(p) for p in im.path] == [str(p) for p in g[t + "_path"]]
+            assert tuple(im.crop_size) == tuple(g[t + "_crop_size"])
+            assert np.array_equal(im.crop_offsets.cpu().numpy(), g[t + "_crop_offsets"])
+            assert tuple(im.x.shape) == tuple(g[t + "_x_shape"])
+            assert np.array_equal(im.x.double().sum(dim=(1, 2, 3)).cpu().numpy(), g[t + "_x_sum"])
+            mo = im.mappings
+            assert np.array_equal(mo.pointers.cpu().numpy(), g[t + "_pointers"])
+            assert np.array_equal(mo.images.cpu().numpy(), g[t + "_images"])
+            vp = g[t + "_view_pointers"]
+            assert np.array_equal(mo.values[1].pointers.cpu().numpy(), vp)
+            assert np.array_equal(mo.pixels.cpu().numpy(), canonical_pixels(vp, g[t + "_pixels"]))
+            np.testing.assert_allclose(mo.features.cpu().numpy(), g[t + "_features"], rtol=1e-6, atol=1e-7)
+    empty = sample()[torch.zeros(0, dtype=torch.long, device=DEV)]
+    _, out = CropImageGroups()(Data(), empty)
+    assert isinstance(out, ImageData) and len(out) == 1 and out[0].num_views == 0

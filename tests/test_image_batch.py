@@ -157,3 +157,33 @@ def test_image_selection_transforms(golden):
     _same_images(out, g, "area_bbox")
     _, out = PickKImages(2)(data, _sample(g))
     assert out.num_views == 3 and [str(p) for p in out.path] == ["v0", "v2", "v4"]
+
+
+# ------------------------------------------------------------- crop groups
+def _crop_sample(g):
+    n_img, (W, H) = int(g["n_img"]), (int(v) for v in g["size"])
+    x = torch.arange(n_img * 2 * H * W, dtype=torch.float32).view(n_img, 2, H, W)
+    return SameSettingImageData(
+        path=[f"v{i}" for i in range(n_img)], pos=T(g["pos_img"]), ref_size=(W, H),
+        proj_upscale=1, downscale=1, mappings=mapping(g, "in_"), x=x)
+
+
+def test_bounding_boxes_and_feature_thresholds(golden):
+    """ImageMapping.bounding_boxes, PickMappingsFromMappingFeatures and
+    JitterMappingFeatures against the reference's own (CropImageGroups, which
+    rebuilds the mappings on the HIP device, is checked in the GPU tests)."""
+    from mvfusion.transforms import JitterMappingFeatures, PickMappingsFromMappingFeatures
+    g = golden("crop_groups")
+    boxes = _crop_sample(g).mappings.bounding_boxes
+    for k, v in zip(("w_min", "w_max", "h_min", "h_max"), boxes):
+        assert np.array_equal(v.numpy(), g["bbox_" + k]) and v.numpy().dtype == g["bbox_" + k].dtype
+    data = _Data(pos=torch.zeros(3, 3))
+    _, out = PickMappingsFromMappingFeatures(feat=[0, 2], lower=[0.2, None], upper=[None, 0.7])(
+        data, _crop_sample(g))
+    assert [str(p) for p in out.path] == [str(p) for p in g["pmf_path"]]
+    same(out.mappings, g, "pmf_")
+    im = _crop_sample(g)
+    before = im.mappings.features.clone()
+    _, im = JitterMappingFeatures(sigma=0.5, clip=0.03)(data, im)
+    d = (im.mappings.features - before).abs()
+    assert 0 < float(d.max()) <= 0.03 + 1e-7
