@@ -35,8 +35,8 @@ for k in sorted(set(fetch) | set(write)):
     w = sum(write[k]) / max(len(write[k]), 1)
     detail[k] = dict(fetch_bytes_x2=f, write_bytes=w, launches_sampled=len(fetch[k]))
     out[STAGE.get(k, k)] = f + w
-# one QKVBimodalCSRPool.forward = all launches between two attention_pool launches
-nfwd = len(fetch.get("attention_pool_kernel", []))
+# one QKVBimodalCSRPool.forward = all launches between two score launches
+nfwd = len(fetch.get("attention_scores_kernel", []))
 if nfwd:
     out["forward"] = sum(2.0 * sum(fetch[k]) + sum(write[k]) for k in set(fetch) | set(write)) / nfwd
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
