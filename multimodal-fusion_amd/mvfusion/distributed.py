@@ -128,3 +128,96 @@ def view_sharded_pool(x_view, view_ptr, group=None, segment_csr=None):
     """View -> point max and mean pools of a scene whose views are sharded over
     the ranks: local pre-reduction + ``combine_view_pools``."""
     return combine_view_pools(*local_view_pools(x_view, view_ptr, segment_csr), group=group)
+
+
+# --------------------------------------------------------------------------- #
+# Attentive pools on a view-sharded scene: view rows travel to point owners     #
+# --------------------------------------------------------------------------- #
+# The attentive pools (QKVBimodalCSRPool, GroupBimodalCSRPool) normalise over
+# all the views of a point, so partial results cannot be combined with a
+# reduction.  Instead the points are block-partitioned over the ranks and every
+# rank sends the view rows it holds (features and mapping features of its own
+# views, in point order) to the rank that owns the point: one all-to-all of row
+# counts and one all-to-all per row tensor.  A rank's rows of one owner are
+# contiguous in its CSR, so nothing is permuted before sending.  The owner
+# interleaves what it receives into one CSR, per point in source-rank order,
+# which is ascending view order because the ranks hold ascending view blocks:
+# the merged rows are exactly the rows of a single-device run, restricted to the
+# owned points, and the pool then runs locally.
+
+def partition_points(num_points, rank=None, world_size=None):
+    """Contiguous, balanced block of point indices owned by this rank."""
+    return partition_views(num_points, rank, world_size)
+
+
+def merge_view_rows(counts, rows):
+    """Interleave per-source CSR blocks over the same points.  ``counts[s]``
+    [n] rows per point from source s, ``rows[s]`` a list of [sum counts[s], *]
+    tensors.  Returns (ptr [n + 1], list of merged tensors): per point the rows
+    of source 0, then source 1, ..."""
+    n = counts[0].shape[0]
+    dev = counts[0].device
+    total = torch.stack(counts, 0).sum(0)
+    ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(total, 0)
+    merged = [torch.empty((int(ptr[-1]),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+              for t in rows[0]]
+    before = torch.zeros(n, dtype=torch.int64, device=dev)      # rows of earlier sources per point
+    for c, block in zip(counts, rows):
+        m = int(c.sum())
+        src_ptr = torch.cumsum(c, 0) - c
+        dest = (ptr[:-1] + before - src_ptr).repeat_interleave(c) + torch.arange(m, device=dev)
+        for out, t in zip(merged, block):
+            assert t.shape[0] == m, "row tensor does not match its counts"
+            out[dest.to(out.device)] = t
+        before = before + c
+    return ptr, merged
+
+
+def exchange_view_rows(view_ptr, rows, group=None):
+    """The exchange step of the attentive pools on a view-sharded scene.
+    ``view_ptr`` [N + 1]: point -> this rank's view rows; ``rows``: list of
+    [Vw_r, *] tensors aligned with it (view features, mapping features, ...).
+    Returns (owned point range, ptr [n_own + 1], merged row tensors): the
+    complete view rows of the points this rank owns, views ascending."""
+    import torch.distributed as dist
+    n = view_ptr.shape[0] - 1
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return range(n), view_ptr, list(rows)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    blocks = [partition_points(n, r, world) for r in range(world)]
+    own = blocks[rank]
+    dev = view_ptr.device
+    counts = (view_ptr[1:] - view_ptr[:-1]).contiguous()
+    # counts of every owner's points: [n] split by owner -> [world * n_own] from every source
+    recv_counts = torch.empty(world * len(own), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv_counts, counts, output_split_sizes=[len(own)] * world,
+                           input_split_sizes=[len(b) for b in blocks], group=group)
+    recv_counts = recv_counts.view(world, len(own))
+    bounds = view_ptr[torch.tensor([b.start for b in blocks] + [n], device=dev)]
+    send_rows = (bounds[1:] - bounds[:-1]).tolist()
+    recv_rows = recv_counts.sum(1).tolist()
+    received = []
+    for t in rows:
+        t = t.contiguous()
+        buf = torch.empty((sum(recv_rows),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(buf, t, output_split_sizes=recv_rows, input_split_sizes=send_rows,
+                               group=group)
+        received.append(buf.split(recv_rows, 0))
+    ptr, merged = merge_view_rows(
+        [recv_counts[s] for s in range(world)],
+        [[received[k][s] for k in range(len(rows))] for s in range(world)])
+    return own, ptr, merged
+
+
+def view_sharded_attentive_pool(pool, x_main, x_mod, x_map, view_ptr, group=None, gather=True):
+    """An attentive pool (``pool(x_main, x_mod, x_map, csr_idx)``) on a scene
+    whose views are sharded over the ranks: ``exchange_view_rows``, the pool on
+    the owned points, and (``gather``) an all-gather of the pooled blocks so that
+    every rank holds [N, C].  ``x_main`` [N, F] is replicated like the cloud."""
+    own, ptr, (x_mod, x_map) = exchange_view_rows(view_ptr, [x_mod, x_map], group)
+    x_main_own = None if x_main is None else x_main[own.start:own.stop]
+    out = pool(x_main_own, x_mod, x_map, ptr)
+    if gather:
+        out, _ = gather_rows(out, group)
+    return out

@@ -147,3 +147,78 @@ def test_view_sharded_pool_world2_gloo():
         np.testing.assert_allclose(r[3], want_mean, rtol=1e-5, atol=1e-6)
     assert np.array_equal(res[0][3], res[1][3])
     assert (want_max[25:] < 0).any() and not want_max[:25].any()
+
+
+# ------------------------------------------------- view rows to point owners
+def _rows_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sees, feats = _view_scene()
+        views = D.partition_views(sees.shape[1])
+        x, ptr = _local_csr(sees, feats, views)
+        view_id = torch.from_numpy(np.broadcast_to(np.arange(sees.shape[1]), sees.shape)[:, list(views)][
+            sees[:, list(views)]].copy())
+        own, optr, (ox, oid) = D.exchange_view_rows(ptr, [x, view_id])
+        # a pool stand-in that needs all the views of a point at once: softmax-weighted sum
+        def pool(x_main, x_mod, x_map, csr):
+            out = torch.zeros(csr.shape[0] - 1, x_mod.shape[1], dtype=torch.float64)
+            for s in range(csr.shape[0] - 1):
+                a, b = int(csr[s]), int(csr[s + 1])
+                if b > a:
+                    w = torch.softmax(x_mod[a:b, 0].double(), 0)
+                    out[s] = (x_mod[a:b].double() * w[:, None]).sum(0) + x_main[s, 0].double()
+            return out
+        x_main = torch.arange(sees.shape[0], dtype=torch.float32)[:, None]
+        pooled = D.view_sharded_attentive_pool(pool, x_main, x, view_id[:, None].float(), ptr)
+        q.put((rank, [own.start, own.stop], optr.numpy(), ox.numpy(), oid.numpy(), pooled.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_merge_view_rows_orders_sources_per_point():
+    c0, c1 = torch.tensor([2, 0, 1, 0]), torch.tensor([1, 0, 0, 3])
+    r0, r1 = torch.tensor([10., 11., 12.]), torch.tensor([20., 21., 22., 23.])
+    ptr, (rows,) = D.merge_view_rows([c0, c1], [[r0], [r1]])
+    assert ptr.tolist() == [0, 3, 3, 4, 7]
+    assert rows.tolist() == [10., 11., 20., 12., 21., 22., 23.]
+    own, p, rws = D.exchange_view_rows(ptr, [rows])          # no process group: identity
+    assert list(own) == [0, 1, 2, 3] and p is ptr and rws[0] is rows
+    assert [list(D.partition_points(10, r, 3)) for r in range(3)] == [[0, 1, 2, 3], [4, 5, 6], [7, 8, 9]]
+
+
+def test_exchange_view_rows_world2_gloo():
+    """Views sharded over two ranks, points block-partitioned: after the exchange
+    every owner holds exactly the rows of a single-process CSR of its points, in
+    ascending view order, and a pool that normalises over all views of a point
+    returns the single-process result on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sees, feats = _view_scene()
+    V = sees.shape[1]
+    x, ptr = _local_csr(sees, feats, range(V))
+    x, ptr = x.numpy(), ptr.numpy()
+    ids = np.broadcast_to(np.arange(V), sees.shape)[sees]
+    n = sees.shape[0]
+    assert [r[1] for r in res] == [[0, (n + 1) // 2], [(n + 1) // 2, n]]
+    for _, (a, b), optr, ox, oid, pooled in res:
+        assert np.array_equal(optr, ptr[a:b + 1] - ptr[a])
+        assert np.array_equal(ox, x[ptr[a]:ptr[b]])
+        assert np.array_equal(oid, ids[ptr[a]:ptr[b]])
+    want = np.zeros((n, x.shape[1]))
+    for s in range(n):
+        a, b = ptr[s], ptr[s + 1]
+        if b > a:
+            w = torch.softmax(torch.from_numpy(x[a:b, 0]).double(), 0).numpy()
+            want[s] = (x[a:b].astype(np.float64) * w[:, None]).sum(0) + s
+    for r in res:
+        np.testing.assert_allclose(r[5], want, rtol=1e-12, atol=1e-12)

@@ -351,3 +351,58 @@ def test_neighborhood_mapping_features():
     assert after.shape[1] == before.shape[1] + 2
     assert np.array_equal(after[:, :before.shape[1]], before)
     np.testing.assert_allclose(after[:, before.shape[1]:], cols, rtol=1e-6, atol=1e-7)
+
+
+def test_view_sharded_attentive_pool_equals_single_pass():
+    """Attentive pool on a view-sharded scene: two blocks of views mapped and
+    pooled to view rows separately (two ranks), the rows of every block of
+    points merged as the all-to-all delivers them to the block's owner, the
+    QKV pool run per owner; against one pass over all views.  The merged rows
+    equal the single-pass rows bit for bit; the pooled features agree to 1e-6 (the
+    32-row tiles of the pool's last launch fall differently on the owner's rows)."""
+    from mvfusion import distributed as D
+    from mvfusion import pooling
+    from mvfusion.pooling import gather_atomic_pool
+    from mvfusion.transforms import MapImages
+    sc = S.make_scene("c1", seed=41)
+    xyz = sc["xyz"]
+    N, (W, H), V, C_feat = xyz.shape[0], sc["img_size"], sc["pos"].shape[0], 8
+    rng = np.random.default_rng(42)
+    x_all = T(rng.normal(size=(V, C_feat, H, W)).astype(np.float32)).to(DEV)
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True,
+                  point_order="index", **VIS)
+
+    def run(view_ids):
+        data, images = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=False)
+        sub = images[torch.as_tensor(list(view_ids))]
+        _, out = t(data, sub)
+        kept = [k for k in range(sub.num_views) if any(torch.equal(sub.pos[k], p) for p in out.pos)]
+        x = x_all[torch.as_tensor(list(view_ids))[kept].to(DEV)]
+        m = out.mappings.to(DEV)
+        return gather_atomic_pool(x, m, "max"), m.features, m.view_csr_indexing
+
+    xv, xm, ptr = run(range(V))
+    torch.manual_seed(3)
+    pool = pooling.QKVBimodalCSRPool(in_main=8, in_map=xm.shape[1], in_mod=C_feat, out_mod=C_feat,
+                                     num_groups=1, nc_qk=8, gating=False).to(DEV).eval()
+    x_main = T(rng.random((N, 8)).astype(np.float32)).to(DEV)
+    want = pool(x_main, xv, xm, ptr)
+    assert float(want.abs().max()) > 0
+    parts = [run(D.partition_views(V, r, 2)) for r in range(2)]
+    outs = []
+    for o in range(2):
+        own = D.partition_points(N, o, 2)
+        counts = [(p[2][1:] - p[2][:-1])[own.start:own.stop] for p in parts]
+        rows = [[p[0][int(p[2][own.start]):int(p[2][own.stop])],
+                 p[1][int(p[2][own.start]):int(p[2][own.stop])]] for p in parts]
+        optr, (ox, om) = D.merge_view_rows(counts, rows)
+        a, b = int(ptr[own.start]), int(ptr[own.stop])
+        assert torch.equal(optr, ptr[own.start:own.stop + 1] - a)
+        assert torch.equal(ox, xv[a:b]) and torch.equal(om, xm[a:b])
+        outs.append(pool(x_main[own.start:own.stop], ox, om, optr))
+    got = torch.cat(outs)
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6 * scale)
+    # single process: the exchange is the identity
+    one = D.view_sharded_attentive_pool(pool, x_main, xv, xm, ptr)
+    assert torch.equal(one, pool(x_main, xv, xm, ptr)) or torch.allclose(one, want, rtol=1e-6, atol=1e-6 * scale)
