@@ -73,9 +73,12 @@ struct MlpArgs {
     // pool_out[s][c] = (sum over the rows r of segment s, in order, of y[r][c] * pool_att[r])
     //                  * pool_gate[s]     (no gate factor when pool_gate == null)
     // with s = dot_seg[r]; rows are grouped by segment, segments ascending.
+    // POOL == 2 (pool_groups > 1 groups of cout / pool_groups channels, a multiple of 4):
+    // pool_att is [rows][pool_groups] and already carries the gate factor.
     const float *pool_att;
     const float *pool_gate;
     float *pool_out;
+    int pool_groups;
 };
 
 // Rows of one staging step of the pool epilogue and the LDS pitch of a staged row.
@@ -265,7 +268,7 @@ __device__ __forceinline__ void mlp_store(
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
 // and LDS offsets become immediates.  NL < 0 is the general kernel that takes
 // everything from the arguments.
-template <int NL, int WMASK, bool POOL = false>
+template <int NL, int WMASK, int POOL = 0>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 {
     constexpr bool FIXED = NL >= 0;
@@ -363,9 +366,19 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         // whether its first / last segment continues in a neighbouring tile
         int pseg = -1, pprev = -1, pnext = -1;
         float patt = 0.f, pgate = 1.f;
+        float pw[8];                                     // POOL == 2: weight of each float4 of channels
         if (POOL) {
             const i64 t0 = base + wave * 32;
-            if (live) { pseg = A.dot_seg[row]; patt = A.pool_att[row]; }
+            if (live) pseg = A.dot_seg[row];
+            if (POOL == 1 && live) patt = A.pool_att[row];
+            if (POOL == 2) {
+                const int cg = A.L[nlayers - 1].cout / A.pool_groups;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
+                    pw[q] = (live && c0 < A.L[nlayers - 1].cout) ? A.pool_att[row * A.pool_groups + c0 / cg] : 0.f;
+                }
+            }
             if (t0 > 0 && t0 < A.rows) pprev = A.dot_seg[t0 - 1];
             if (t0 + POOL_TILE < A.rows) pnext = A.dot_seg[t0 + POOL_TILE];
         }
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             }
             if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
-        if (POOL && A.pool_gate && live) pgate = A.pool_gate[pseg];
+        if (POOL == 1 && A.pool_gate && live) pgate = A.pool_gate[pseg];
         if (A.dot_out) {
             const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
             const int cq = A.L[nlayers - 1].cout;
@@ -536,7 +549,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             float accv = 0.f;
             auto flush = [&](int seg, float v, bool part, float gate_) {
                 if (seg < 0 || lane >= cout) return;
-                if (A.pool_gate) v = __fmul_rn(v, gate_);
+                if (POOL == 1 && A.pool_gate) v = __fmul_rn(v, gate_);
                 float *o = A.pool_out + (size_t)seg * cout + lane;
                 if (part) unsafeAtomicAdd(o, v);
                 else *o = v;
@@ -546,16 +559,20 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                 if ((jrow >> 4) == half) {
                     float *p = stg + (jrow & 15) * POOL_PITCH + 4 * kh;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                    for (int g = 0; g < 4; ++g) {
+                        const float w = POOL == 2 ? pw[g] : patt;
                         *(float4 *)(p + 8 * g) = make_float4(
-                            __fmul_rn(acc0[4 * g], patt), __fmul_rn(acc0[4 * g + 1], patt),
-                            __fmul_rn(acc0[4 * g + 2], patt), __fmul_rn(acc0[4 * g + 3], patt));
+                            __fmul_rn(acc0[4 * g], w), __fmul_rn(acc0[4 * g + 1], w),
+                            __fmul_rn(acc0[4 * g + 2], w), __fmul_rn(acc0[4 * g + 3], w));
+                    }
                     if (wide) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
+                        for (int g = 0; g < 4; ++g) {
+                            const float w = POOL == 2 ? pw[4 + g] : patt;
                             *(float4 *)(p + 32 + 8 * g) = make_float4(
-                                __fmul_rn(acc1[4 * g], patt), __fmul_rn(acc1[4 * g + 1], patt),
-                                __fmul_rn(acc1[4 * g + 2], patt), __fmul_rn(acc1[4 * g + 3], patt));
+                                __fmul_rn(acc1[4 * g], w), __fmul_rn(acc1[4 * g + 1], w),
+                                __fmul_rn(acc1[4 * g + 2], w), __fmul_rn(acc1[4 * g + 3], w));
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -640,17 +657,21 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
     const float *__restrict__ comp, float *__restrict__ att, float *__restrict__ gate,
     float *__restrict__ pool_out, int pool_C)
 {
+    // pool_out != null: the launch prepares the pool epilogue of the layer chain.  The
+    // rows of empty segments and of segments that cross a tile boundary start from zero
+    // (thread (s, g) clears the channels of group g), and with more than one group the
+    // gate is folded into the attention weights.
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= nseg * G) return;
     const i64 s = t / G;
     const int g = (int)(t - s * G);
     const i64 a = ptr[s], b = ptr[s + 1];
-    // Ahead of the pool epilogue of the layer chain (G == 1): the rows of empty segments
-    // and of segments that cross a tile boundary start from zero.
-    if (pool_out && (b <= a || a / POOL_TILE != (b - 1) / POOL_TILE)) {
-        float *o = pool_out + (size_t)s * pool_C;
-        for (int c = 0; c < pool_C; ++c) o[c] = 0.f;
+        if (pool_out && (b <= a || a / POOL_TILE != (b - 1) / POOL_TILE)) {
+        const int cg = pool_C / G;
+        float *o = pool_out + (size_t)s * pool_C + (size_t)g * cg;
+        for (int c = 0; c < cg; ++c) o[c] = 0.f;
     }
+    float fold = 1.f;
     float mx = 0.f;                                    // segment max of nothing is 0
     for (i64 r = a; r < b; ++r) {
         const float c = comp[(size_t)r * G + g];
@@ -660,8 +681,10 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         float x = mx;
         if (gate_w) x = __fmul_rn(x, gate_w[g]);
         if (gate_b) x = __fadd_rn(x, gate_b[g]);
-        gate[t] = tanhf(x > 0.f ? x : 0.f);
+        fold = tanhf(x > 0.f ? x : 0.f);
+        gate[t] = fold;
     }
+    if (!(pool_out && G > 1 && gate)) fold = 1.f;
     if (b <= a) return;
     const float sq = sqrtf((float)(b - a));
     float sum = 0.f;
@@ -673,7 +696,12 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         sum = (r == a) ? e : __fadd_rn(sum, e);
     }
     sum = __fadd_rn(sum, eps);
-    for (i64 r = a; r < b; ++r) att[(size_t)r * G + g] = __fdiv_rn(att[(size_t)r * G + g], sum);
+    if (fold == 1.f) {
+        for (i64 r = a; r < b; ++r) att[(size_t)r * G + g] = __fdiv_rn(att[(size_t)r * G + g], sum);
+    } else {
+        for (i64 r = a; r < b; ++r)
+            att[(size_t)r * G + g] = __fmul_rn(__fdiv_rn(att[(size_t)r * G + g], sum), fold);
+    }
 }
 
 // x_pool[s][c] = (sum_r x[r][c] * att[r][group(c)]) * gate[s][group(c)], rows
@@ -824,7 +852,8 @@ static int mlp_forward_impl(
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
     float dot_div, float *dot_out, void *stream,
-    const float *pool_att = nullptr, const float *pool_gate = nullptr, float *pool_out = nullptr)
+    const float *pool_att = nullptr, const float *pool_gate = nullptr, float *pool_out = nullptr,
+    int32_t pool_groups = 1)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
@@ -833,6 +862,9 @@ static int mlp_forward_impl(
     MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out || pool_out), "mlp_forward: bad first input");
     if (pool_out) {
         MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
+        const int co = layers[nlayers - 1].cout;
+        MVF_REQUIRE(pool_groups >= 1 && (pool_groups == 1 || (!pool_gate && co % pool_groups == 0 && (co / pool_groups) % 4 == 0)),
+                    "mlp_forward_pool: %d groups need equal groups of a multiple of 4 channels and the gate folded into att", pool_groups);
         out = pool_out; ldo = layers[nlayers - 1].cout;                 // never written through `out`
     }
     if (dot_out) {
@@ -868,7 +900,7 @@ static int mlp_forward_impl(
     A.out = out;
     A.ldo = ldo;
     A.dot_q = dot_q; A.dot_seg = dot_seg; A.dot_ldq = dot_ldq; A.dot_div = dot_div; A.dot_out = dot_out;
-    A.pool_att = pool_att; A.pool_gate = pool_gate; A.pool_out = pool_out;
+    A.pool_att = pool_att; A.pool_gate = pool_gate; A.pool_out = pool_out; A.pool_groups = pool_groups;
     if (pool_out) A.dot_seg = dot_seg;
     A.debug = 0;
 #ifdef MVF_MLP_DEBUG
@@ -906,17 +938,22 @@ static int mlp_forward_impl(
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
         hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_>), grid, dim3(MLP_THREADS), lds, st, A);   \
     } while (0)
-#define MVF_MLP_LAUNCH_POOL(NL_, WM_)                                                            \
+#define MVF_MLP_LAUNCH_POOL(NL_, WM_, P_)                                                        \
     do {                                                                                         \
-        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, true>,              \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, P_>,                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, true>), grid, dim3(MLP_THREADS), lds, st, A); \
+        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, P_>), grid, dim3(MLP_THREADS), lds, st, A); \
     } while (0)
     if (pool_out) {
         MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
                     "mlp_forward_pool: two layers of equal output width on 16-byte aligned, unsummed inputs only");
-        if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0);
-        else MVF_MLP_LAUNCH_POOL(2, 3);
+        if (pool_groups == 1) {
+            if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0, 1);
+            else MVF_MLP_LAUNCH_POOL(2, 3, 1);
+        } else {
+            if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0, 2);
+            else MVF_MLP_LAUNCH_POOL(2, 3, 2);
+        }
     } else if (!fixed) MVF_MLP_LAUNCH(-1, 0);
     else switch (nlayers * 8 + wmask) {
     case 8 + 0: MVF_MLP_LAUNCH(1, 0); break;
@@ -966,11 +1003,11 @@ extern "C" int mvf_mlp_forward_pool(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    const float *att, const int32_t *row2seg, const float *gate, float *pool_out, void *stream)
+    const float *att, int32_t G, const int32_t *row2seg, const float *gate, float *pool_out, void *stream)
 {
     MVF_REQUIRE(pool_out, "mlp_forward_pool: null output");
     return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
-                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, gate, pool_out);
+                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, gate, pool_out, G);
 }
 
 extern "C" int mvf_attention_pool(
@@ -989,7 +1026,8 @@ extern "C" int mvf_attention_pool(
     MVF_REQUIRE(ptr && out && (rows == 0 || (comp && att)), "attention_pool: null buffer");
     // x_mod == NULL: scores only; `out` is prepared for mvf_mlp_forward_pool
     const bool prepare = x_mod == nullptr && rows > 0;
-    MVF_REQUIRE(!prepare || G == 1, "attention_pool: the fused pool handles one group");
+    MVF_REQUIRE(!prepare || G == 1 || (C % G == 0 && (C / G) % 4 == 0),
+                "attention_pool: the fused pool needs equal groups of a multiple of 4 channels");
     hipStream_t st = (hipStream_t)stream;
     if (keys && rows > 0) {
         const float dim_div = dim_scaling ? (float)sqrt((double)D) : 0.f;

@@ -118,8 +118,8 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
             L.check(lib.mvf_mlp_forward_pool(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
                 L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
-                L.ptr(gb), rows, arr, len(specs), L.ptr(att), L.ptr(seg), L.ptr(gate),
-                L.ptr(out), L.stream_ptr(dev)))
+                L.ptr(gb), rows, arr, len(specs), L.ptr(att), att.shape[1], L.ptr(seg),
+                L.ptr(gate if att.shape[1] == 1 else None), L.ptr(out), L.stream_ptr(dev)))
         elif dot is None:
             L.check(lib.mvf_mlp_forward(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
@@ -211,8 +211,10 @@ def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0, dot=Non
 def pool_fusable(specs, x, num_groups):
     """Can pooled_layers() run these layers with the attention-weighted segment
     sum as their epilogue?  Two layers of one output width <= 64 (a multiple of
-    4) on an aligned float32 input, one attention group."""
-    return (num_groups == 1 and len(specs) == 2 and specs[0].cout == specs[1].cout
+    4) on an aligned float32 input; attention groups of equally many channels, a
+    multiple of 4."""
+    return (len(specs) == 2 and specs[0].cout == specs[1].cout
+            and specs[1].cout % num_groups == 0 and (specs[1].cout // num_groups) % 4 == 0
             and specs[1].cout <= _MAX_C and specs[1].cout % 4 == 0
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
             and x.shape[1] % 8 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -221,7 +223,9 @@ def pool_fusable(specs, x, num_groups):
 
 def pooled_layers(specs, x, att, row2seg, gate, out):
     """out[s] = (sum_{r in s} specs(x)[r] * att[r]) * gate[s]: the layer chain with
-    the pool epilogue (needs pool_fusable; `out` prepared by attention_pool(None, ...))."""
+    the pool epilogue (needs pool_fusable; `att` [rows, G], `gate` and `out` as
+    returned by attention_pool(<number of channels>, ...): with more than one
+    group that `att` already carries the gate)."""
     _launch((x.detach(), None, None, None, 0), [(sp, 0, sp.cout) for sp in specs], None, out,
             specs[-1].cout, pool=(att, row2seg, gate))
     return out
@@ -244,8 +248,9 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
     """Returns (x_pool, comp, att, gate).  Either ``keys``/``queries`` or
     ``comp`` (the compatibilities) is given; ``row2seg`` maps key rows to query
     rows (None: one query row per key row).  ``x_mod`` may be the number of
-    value channels instead of the values (one group only): the scores are
-    computed and x_pool comes back prepared for pooled_layers()."""
+    value channels instead of the values: the scores are computed and x_pool
+    comes back prepared for pooled_layers() (with more than one group ``att``
+    then holds att * gate)."""
     lib = L.load()
     if isinstance(x_mod, int):
         src = keys if keys is not None else comp

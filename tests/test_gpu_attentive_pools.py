@@ -221,15 +221,17 @@ def test_mlp_chain_dot_epilogue():
             assert err <= 1e-5 * max(want.abs().max().item(), 1e-3), (rows, chans, D, err)
 
 
-@pytest.mark.parametrize("C,gating", [(64, True), (32, True), (48, False), (8, True)])
-def test_mlp_chain_pool_epilogue(C, gating):
+@pytest.mark.parametrize("C,gating,G", [(64, True, 1), (32, True, 1), (48, False, 1), (8, True, 1),
+                                        (64, True, 4), (64, False, 16), (48, True, 4), (32, True, 2)])
+def test_mlp_chain_pool_epilogue(C, gating, G):
     """The value encoder with the attention-weighted segment sum as epilogue
     against encoder launch + attention_pool on the same compatibilities:
     identical bits for every segment inside one 32-row tile, 1e-6 of the output
     scale for the segments that cross a tile boundary; empty segments, segments of
-    more than 64 rows (three tiles) and a ragged last tile included.  Then the two
-    modules that use it, with and without save_last (which keeps the unfused
-    launches)."""
+    more than 64 rows (three tiles) and a ragged last tile included.  With more
+    than one group the gate is folded into the attention weights, so every
+    segment is compared at 1e-6.  Then the two modules that use it, with and
+    without save_last (which keeps the unfused launches)."""
     from mvfusion import dense
     rng = np.random.default_rng(11)
     N = 30011
@@ -240,21 +242,26 @@ def test_mlp_chain_pool_epilogue(C, gating):
     ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     Vw = int(ptr[-1])
     x_mod = T((rng.random((Vw, C)) - 0.3).astype(np.float32))
-    comp = T((rng.random((Vw, 1)) * 2 - 1).astype(np.float32))
+    comp = T((rng.random((Vw, G)) * 2 - 1).astype(np.float32))
+    c2g = None if G == 1 else torch.arange(G, dtype=torch.int32, device=DEV).repeat_interleave(C // G)
     dptr = T(ptr)
     torch.manual_seed(C)
     e_mod = _random_module(pooling.MLP([C, C, C], bias=False), 3).to(DEV).eval()
     specs = dense.mlp_layers(e_mod)
-    assert dense.pool_fusable(specs, x_mod, 1)
+    assert dense.pool_fusable(specs, x_mod, G)
     kw = dict(comp=comp, group_scaling=True, gating=gating,
-              gate_w=torch.tensor([[1.3]], device=DEV) if gating else None,
-              gate_b=torch.tensor([[0.1]], device=DEV) if gating else None)
-    plain, _, att, gate = dense.attention_pool(dense.run_layers(specs, x_mod), dptr, 1, None, **kw)
+              gate_w=torch.linspace(1.0, 1.6, G, device=DEV)[None] if gating else None,
+              gate_b=torch.linspace(-0.1, 0.1, G, device=DEV)[None] if gating else None)
+    plain, _, att, gate = dense.attention_pool(dense.run_layers(specs, x_mod), dptr, G, c2g, **kw)
     row2seg = dense.csr_row_segments(dptr, Vw)
 
     def fused_pass():
-        out, _, att2, gate2 = dense.attention_pool(C, dptr, 1, None, **kw)
-        assert torch.equal(att2, att) and (gate is None or torch.equal(gate2, gate))
+        out, _, att2, gate2 = dense.attention_pool(C, dptr, G, c2g, **kw)
+        assert gate is None or torch.equal(gate2, gate)
+        if G == 1 or gate is None:
+            assert torch.equal(att2, att)
+        else:
+            assert torch.equal(att2, att * gate[row2seg.long()])
         return dense.pooled_layers(specs, x_mod, att2, row2seg, gate2, out)
 
     fused, again = fused_pass(), fused_pass()
@@ -263,7 +270,8 @@ def test_mlp_chain_pool_epilogue(C, gating):
     two_tiles = (ptr[:-1] // 32 + 1 == (ptr[1:] - 1) // 32)
     assert inside.sum() > 0.8 * N and (~inside).sum() > 100
     m = torch.from_numpy(inside).to(DEV)
-    assert torch.equal(fused[m], plain[m])
+    if G == 1 or not gating:
+        assert torch.equal(fused[m], plain[m])
     _close(fused, plain.cpu().numpy(), rtol=1e-6)
     assert float(fused[T(counts == 0)].abs().max()) == 0.0
     # run to run: only sums of three or more tile partials may change bits
@@ -275,9 +283,9 @@ def test_mlp_chain_pool_epilogue(C, gating):
     x_main = T(rng.random((N, 16)).astype(np.float32))
     x_map = T(rng.random((Vw, 8)).astype(np.float32))
     qkv = _random_module(pooling.QKVBimodalCSRPool(
-        in_main=16, in_map=8, in_mod=C, out_mod=C, num_groups=1, nc_qk=8, gating=False), 3).to(DEV).eval()
+        in_main=16, in_map=8, in_mod=C, out_mod=C, num_groups=G, nc_qk=8, gating=False), 3).to(DEV).eval()
     grp = _random_module(pooling.GroupBimodalCSRPool(
-        in_map=8, in_mod=C, num_groups=1, gating=False, group_scaling=True), 4).to(DEV).eval()
+        in_map=8, in_mod=C, num_groups=G, gating=False, group_scaling=True), 4).to(DEV).eval()
     for mod, args in ((qkv, (x_main, x_mod, x_map, dptr)), (grp, (None, x_mod, x_map, dptr))):
         a = mod(*args)
         mod.save_last = True
