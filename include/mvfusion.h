@@ -343,7 +343,7 @@ int mvf_mlp_forward_dot(
  * i.e. pooling.py:519-530 / :295-300 without the [rows][cout] values leaving
  * the chip.  row2seg maps rows to segments (rows grouped by segment,
  * ascending).  att is [rows][G].  G == 1: gate [nseg] or NULL (no gate
- * factor).  G > 1: groups of cout / G consecutive channels (cout % G == 0,
+ * factor).  1 < G <= 8: groups of cout / G consecutive channels (cout % G == 0,
  * a multiple of 4 channels per group), gate must be NULL and att already holds
  * att * gate.  att and pool_out must come from mvf_attention_pool(x_mod =
  * NULL), which folds the gate that way and zeroes the rows the epilogue adds to
@@ -372,7 +372,7 @@ int mvf_mlp_forward_pool(
  * may keep (the modules' save_last tensors).  chan2group may be NULL when G == 1.
  * x_mod == NULL with rows > 0: comp, att and gate are computed and `out` [nseg][C]
  * is prepared for mvf_mlp_forward_pool, which then produces the sum (G > 1
- * needs C % G == 0 and (C / G) % 4 == 0; att then comes back times the gate). */
+ * needs G <= 8, C % G == 0 and (C / G) % 4 == 0; att then comes back times the gate). */
 int mvf_attention_pool(
     const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
     const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,

@@ -35,8 +35,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #ifdef MVF_MLP_DEBUG
 static int g_mlp_debug;          // host side; bit 0: no output stores, bit 1: no input loads
 #define MLPD(A_, bit) ((A_).debug & (bit))
+#define MLP_DBG(A_) ((A_).debug)
 #else
 #define MLPD(A_, bit) false
+#define MLP_DBG(A_) 0          // a compile-time zero: the phase switches vanish from the layer loops
 #endif
 
 constexpr int MLP_THREADS = 256;
@@ -87,6 +89,9 @@ constexpr int POOL_PITCH = MLP_MAX_C + 4;
 // Segments are folded inside tiles of this many rows (one wave's rows); a segment that
 // crosses a tile boundary is completed with atomic adds and must start from zero.
 constexpr int POOL_TILE = 32;
+// Most attention groups the pool epilogue takes (their weights of a tile are parked in the
+// staging rows, two groups per lane and load).
+constexpr int POOL_MAX_GROUPS = 8;
 
 __host__ __device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
 // LDS rows of a layer's transposed weights
@@ -174,18 +179,12 @@ __device__ __forceinline__ void mlp_epilogue(
 // scale and the accumulators start from the channel shift.
 __device__ __forceinline__ void mlp_epilogue4(floatx16 &acc, int g, const mvf_mlp_layer &L)
 {
-    if (!L.act) return;
-    if (L.slope >= 0.f && L.slope <= 1.f) {
-        // leaky(v) = max(v, slope * v) for a slope in [0, 1]
+    // leaky(v) = max(v, slope * v) for every slope <= 1 (the host rejects larger ones);
+    // no activation is slope 1.  One straight line of code for every layer: a branch on the
+    // layer's settings here makes the compiler copy the whole accumulator block around it.
+    const float s = L.act ? L.slope : 1.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = fmaxf(acc[4 * g + e], __fmul_rn(acc[4 * g + e], L.slope));
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = acc[4 * g + e];
-            acc[4 * g + e] = v > 0.f ? v : __fmul_rn(v, L.slope);
-        }
-    }
+    for (int e = 0; e < 4; ++e) acc[4 * g + e] = fmaxf(acc[4 * g + e], __fmul_rn(acc[4 * g + e], s));
 }
 
 // Accumulators of block nb start from the channel shifts of the layer.
@@ -268,8 +267,8 @@ __device__ __forceinline__ void mlp_store(
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
 // and LDS offsets become immediates.  NL < 0 is the general kernel that takes
 // everything from the arguments.
-template <int NL, int WMASK, int POOL = 0>
-__global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
+template <int NL, int WMASK, int POOL>
+__device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
 {
     constexpr bool FIXED = NL >= 0;
     const int nlayers = FIXED ? NL : A.nlayers;
@@ -366,17 +365,20 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         // whether its first / last segment continues in a neighbouring tile
         int pseg = -1, pprev = -1, pnext = -1;
         float patt = 0.f, pgate = 1.f;
-        float pw[8];                                     // POOL == 2: weight of each float4 of channels
+        // POOL == 2: the [32][groups] attention weights of the wave's rows are contiguous in
+        // memory; they are fetched here with coalesced loads, parked in the (idle) staging rows
+        // after the first layer and picked up per lane right before the epilogue
+        float pa[POOL_MAX_GROUPS / 2];
         if (POOL) {
             const i64 t0 = base + wave * 32;
             if (live) pseg = A.dot_seg[row];
             if (POOL == 1 && live) patt = A.pool_att[row];
             if (POOL == 2) {
-                const int cg = A.L[nlayers - 1].cout / A.pool_groups;
+                const i64 first = t0 * A.pool_groups, stop = A.rows * A.pool_groups;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
-                    pw[q] = (live && c0 < A.L[nlayers - 1].cout) ? A.pool_att[row * A.pool_groups + c0 / cg] : 0.f;
+                for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k) {
+                    const int idx = lane + 64 * k;
+                    pa[k] = (idx < 32 * A.pool_groups && first + idx < stop) ? A.pool_att[first + idx] : 0.f;
                 }
             }
             if (t0 > 0 && t0 < A.rows) pprev = A.dot_seg[t0 - 1];
@@ -443,6 +445,12 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
         if (POOL == 1 && A.pool_gate && live) pgate = A.pool_gate[pseg];
+        if (POOL == 2) {
+            float *stg_att = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
+#pragma unroll
+            for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k)
+                if (lane + 64 * k < 32 * A.pool_groups) stg_att[lane + 64 * k] = pa[k];
+        }
         if (A.dot_out) {
             const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
             const int cq = A.L[nlayers - 1].cout;
@@ -472,8 +480,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                 // last layer with two output blocks: n0 first, then n1 while the
                 // finished n0 is scaled and stored group by group
                 const mvf_mlp_layer &L2 = A.L[l + 1];
-                mlp_next_block<1>(acc0, 0, wp, cop2, true, L, n0, n1, nothing, A.debug);
-                if (wide_in) mlp_next_block<1>(acc1, 1, wp, cop2, true, L, n0, n1, nothing, A.debug);
+                mlp_next_block<1>(acc0, 0, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A));
+                if (wide_in) mlp_next_block<1>(acc1, 1, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A));
                 const int per = wide_in ? 2 : 1;      // n1 groups per n0 group
                 auto drain = [&](int step) {
                     if ((step + 1) % per == 0) {
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                         if (!POOL && live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
                     }
                 };
-                mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, A.debug);
-                if (wide_in) mlp_next_block<2>(acc1, 1, wp, cop2, true, L, n0, n1, drain, A.debug);
+                mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A));
+                if (wide_in) mlp_next_block<2>(acc1, 1, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     mlp_epilogue4(n1, g, L2);
@@ -493,8 +501,8 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                 if (POOL) goto pool_tail;
                 goto tile_done;
             }
-            mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, A.debug);
-            if (wide_in) mlp_next_block<0>(acc1, 1, wp, cop2, wide_out, L, n0, n1, nothing, A.debug);
+            mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A));
+            if (wide_in) mlp_next_block<0>(acc1, 1, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A));
             acc0 = n0;
             acc1 = n1;
         }
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         if (POOL) {
             // Attention-weighted segment sum of the finished rows (pooling.py:519-530).
             // The wave's 32 rows go through LDS 16 at a time: a lane writes the 32 / 64
-            // channels of its row (times the row's attention weight), then lane c folds
+            // channels of its row (already times the row's attention weight), then lane c folds
             // channel c over the staged rows in row order.  The segment of a row is
             // wave-uniform (read from the row's lane), so segment changes are scalar
             // branches.  A segment that lies inside the tile is stored; one that
@@ -544,6 +552,35 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
             const bool wide = cop_of(nlayers - 1) > 32;
             const int cout = A.L[nlayers - 1].cout;
             float *stg = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
+            // rows times their attention weights, in place (POOL == 2: one weight per float4
+            // of channels, picked up from the parked [32][groups] block)
+            if (POOL == 2) {
+                // c0 / (cout / groups) as a multiply and shift, exact for c0 < 64
+                const unsigned inv = (65536u + (unsigned)(cout / A.pool_groups) - 1u) / (unsigned)(cout / A.pool_groups);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
+                    if (q >= 4 && !wide) break;
+                    const float w = c0 < cout ? stg[jrow * A.pool_groups + (int)(((unsigned)c0 * inv) >> 16)] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (q < 4) acc0[4 * (q & 3) + e] = __fmul_rn(acc0[4 * (q & 3) + e], w);
+                        else acc1[4 * (q & 3) + e] = __fmul_rn(acc1[4 * (q & 3) + e], w);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc0[r] = __fmul_rn(acc0[r], patt);
+                    if (wide) acc1[r] = __fmul_rn(acc1[r], patt);
+                }
+            }
             int cur = __builtin_amdgcn_readlane(pseg, 0);
             bool partial = cur == pprev;                 // the current segment began before this tile
             float accv = 0.f;
@@ -559,20 +596,12 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
                 if ((jrow >> 4) == half) {
                     float *p = stg + (jrow & 15) * POOL_PITCH + 4 * kh;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float w = POOL == 2 ? pw[g] : patt;
-                        *(float4 *)(p + 8 * g) = make_float4(
-                            __fmul_rn(acc0[4 * g], w), __fmul_rn(acc0[4 * g + 1], w),
-                            __fmul_rn(acc0[4 * g + 2], w), __fmul_rn(acc0[4 * g + 3], w));
-                    }
+                    for (int g = 0; g < 4; ++g)
+                        *(float4 *)(p + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
                     if (wide) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const float w = POOL == 2 ? pw[4 + g] : patt;
-                            *(float4 *)(p + 32 + 8 * g) = make_float4(
-                                __fmul_rn(acc1[4 * g], w), __fmul_rn(acc1[4 * g + 1], w),
-                                __fmul_rn(acc1[4 * g + 2], w), __fmul_rn(acc1[4 * g + 3], w));
-                        }
+                        for (int g = 0; g < 4; ++g)
+                            *(float4 *)(p + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -604,6 +633,22 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
         }
     tile_done:;
     }
+}
+
+template <int NL, int WMASK>
+__global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
+{
+    mlp_chain_body<NL, WMASK, 0>(A);
+}
+
+// The pool epilogue's staging rows leave LDS for three workgroups per CU; the register
+// budget is held to the same three waves per SIMD (the scheduler otherwise spends registers
+// on early weight reads and drops to two).
+template <int NL, int WMASK, int POOL>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
+void mlp_chain_pool_kernel(MlpArgs A)
+{
+    mlp_chain_body<NL, WMASK, POOL>(A);
 }
 
 // ------------------------------------------------------------------------- //
@@ -863,8 +908,10 @@ static int mlp_forward_impl(
     if (pool_out) {
         MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
         const int co = layers[nlayers - 1].cout;
-        MVF_REQUIRE(pool_groups >= 1 && (pool_groups == 1 || (!pool_gate && co % pool_groups == 0 && (co / pool_groups) % 4 == 0)),
-                    "mlp_forward_pool: %d groups need equal groups of a multiple of 4 channels and the gate folded into att", pool_groups);
+        static_assert(32 * POOL_MAX_GROUPS <= POOL_STAGE_ROWS * POOL_PITCH, "the weights of a tile are parked in its staging rows");
+        MVF_REQUIRE(pool_groups >= 1 && pool_groups <= POOL_MAX_GROUPS &&
+                    (pool_groups == 1 || (!pool_gate && co % pool_groups == 0 && (co / pool_groups) % 4 == 0)),
+                    "mlp_forward_pool: %d groups; at most 8 equal groups of a multiple of 4 channels, the gate folded into att", pool_groups);
         out = pool_out; ldo = layers[nlayers - 1].cout;                 // never written through `out`
     }
     if (dot_out) {
@@ -886,6 +933,8 @@ static int mlp_forward_impl(
                     l, layers[l].cin, layers[l].cout);
         MVF_REQUIRE(l == 0 || (layers[l].cin == layers[l - 1].cout && layers[l].cin <= MLP_MAX_C),
                     "mlp_forward: layer %d input width %d does not chain", l, layers[l].cin);
+        MVF_REQUIRE(!layers[l].act || layers[l].slope <= 1.f,
+                    "mlp_forward: layer %d has a LeakyReLU slope %g > 1", l, (double)layers[l].slope);
         MVF_REQUIRE(!layers[l].bn_weight || (layers[l].bn_bias && layers[l].bn_mean && layers[l].bn_var),
                     "mlp_forward: layer %d has partial batch-norm parameters", l);
     }
@@ -940,9 +989,9 @@ static int mlp_forward_impl(
     } while (0)
 #define MVF_MLP_LAUNCH_POOL(NL_, WM_, P_)                                                        \
     do {                                                                                         \
-        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, P_>,                \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_pool_kernel<NL_, WM_, P_>,                \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, P_>), grid, dim3(MLP_THREADS), lds, st, A); \
+        hipLaunchKernelGGL((mlp_chain_pool_kernel<NL_, WM_, P_>), grid, dim3(MLP_THREADS), lds, st, A); \
     } while (0)
     if (pool_out) {
         MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
@@ -1026,8 +1075,8 @@ extern "C" int mvf_attention_pool(
     MVF_REQUIRE(ptr && out && (rows == 0 || (comp && att)), "attention_pool: null buffer");
     // x_mod == NULL: scores only; `out` is prepared for mvf_mlp_forward_pool
     const bool prepare = x_mod == nullptr && rows > 0;
-    MVF_REQUIRE(!prepare || G == 1 || (C % G == 0 && (C / G) % 4 == 0),
-                "attention_pool: the fused pool needs equal groups of a multiple of 4 channels");
+    MVF_REQUIRE(!prepare || G == 1 || (G <= POOL_MAX_GROUPS && C % G == 0 && (C / G) % 4 == 0),
+                "attention_pool: the fused pool needs at most 8 equal groups of a multiple of 4 channels");
     hipStream_t st = (hipStream_t)stream;
     if (keys && rows > 0) {
         const float dim_div = dim_scaling ? (float)sqrt((double)D) : 0.f;

@@ -211,9 +211,9 @@ def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0, dot=Non
 def pool_fusable(specs, x, num_groups):
     """Can pooled_layers() run these layers with the attention-weighted segment
     sum as their epilogue?  Two layers of one output width <= 64 (a multiple of
-    4) on an aligned float32 input; attention groups of equally many channels, a
-    multiple of 4."""
-    return (len(specs) == 2 and specs[0].cout == specs[1].cout
+    4) on an aligned float32 input; at most 8 attention groups of equally many channels,
+    a multiple of 4."""
+    return (len(specs) == 2 and specs[0].cout == specs[1].cout and num_groups <= 8
             and specs[1].cout % num_groups == 0 and (specs[1].cout // num_groups) % 4 == 0
             and specs[1].cout <= _MAX_C and specs[1].cout % 4 == 0
             and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1

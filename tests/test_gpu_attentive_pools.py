@@ -222,7 +222,7 @@ def test_mlp_chain_dot_epilogue():
 
 
 @pytest.mark.parametrize("C,gating,G", [(64, True, 1), (32, True, 1), (48, False, 1), (8, True, 1),
-                                        (64, True, 4), (64, False, 16), (48, True, 4), (32, True, 2)])
+                                        (64, True, 4), (64, False, 8), (48, True, 4), (32, True, 2)])
 def test_mlp_chain_pool_epilogue(C, gating, G):
     """The value encoder with the attention-weighted segment sum as epilogue
     against encoder launch + attention_pool on the same compatibilities:
