@@ -339,24 +339,23 @@ int mvf_mlp_forward_dot(
 /* The same chain (two layers of equal output width <= 64: E_mod, pooling.py:757,
  * 482-484; mode 0 inputs, 16-byte aligned) with the attention-weighted segment
  * sum as epilogue: the encoded view features are not stored; instead
- *   pool_out[s][c] = (sum over the rows r of segment s of y[r][c] * att[r][group(c)]) * gate[s]
+ *   pool_out[s][c] = sum over the rows r of segment s of y[r][c] * att[r][group(c)]
  * i.e. pooling.py:519-530 / :295-300 without the [rows][cout] values leaving
  * the chip.  row2seg maps rows to segments (rows grouped by segment,
- * ascending).  att is [rows][G].  G == 1: gate [nseg] or NULL (no gate
- * factor).  1 < G <= 8: groups of cout / G consecutive channels (cout % G == 0,
- * a multiple of 4 channels per group), gate must be NULL and att already holds
- * att * gate.  att and pool_out must come from mvf_attention_pool(x_mod =
- * NULL), which folds the gate that way and zeroes the rows the epilogue adds to
- * atomically: segments are folded in row order inside tiles of 32 rows, a
- * segment crossing a tile boundary is the sum of per-tile partial sums, so it
- * may differ from mvf_attention_pool's result in the last bits; with G == 1
- * every other segment is bit-identical to it. */
+ * ascending).  att is [rows][G], G <= 8 groups of cout / G consecutive channels
+ * (cout % G == 0, a multiple of 4 channels per group unless G == 1), and
+ * already holds att * gate.  att and pool_out must come from
+ * mvf_attention_pool(x_mod = NULL), which folds the gate that way and zeroes
+ * the rows the epilogue adds to atomically: segments are folded in row order
+ * inside tiles of 32 rows, a segment crossing a tile boundary is the sum of
+ * per-tile partial sums.  Results agree with mvf_attention_pool's to float32
+ * rounding (bit for bit when there is no gate and the segment lies inside one
+ * tile). */
 int mvf_mlp_forward_pool(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    const float *att, int32_t G, const int32_t *row2seg, const float *gate, float *pool_out,
-    void *stream);
+    const float *att, int32_t G, const int32_t *row2seg, float *pool_out, void *stream);
 
 /* The attention tail shared by QKVBimodalCSRPool.forward (pooling.py:503-530)
  * and GroupBimodalCSRPool.forward (pooling.py:284-300):
@@ -371,8 +370,9 @@ int mvf_mlp_forward_pool(
  * comp / att are [rows][G], gate is [nseg][G]; they are outputs the caller
  * may keep (the modules' save_last tensors).  chan2group may be NULL when G == 1.
  * x_mod == NULL with rows > 0: comp, att and gate are computed and `out` [nseg][C]
- * is prepared for mvf_mlp_forward_pool, which then produces the sum (G > 1
- * needs G <= 8, C % G == 0 and (C / G) % 4 == 0; att then comes back times the gate). */
+ * is prepared for mvf_mlp_forward_pool, which then produces the sum; att comes
+ * back times the gate of its segment (G > 1 needs G <= 8, C % G == 0 and
+ * (C / G) % 4 == 0). */
 int mvf_attention_pool(
     const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
     const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,

@@ -72,13 +72,12 @@ struct MlpArgs {
     float dot_div;
     float *dot_out;
     // pool epilogue (pool_out != null; POOL kernels): the last layer's output y is not stored;
-    // pool_out[s][c] = (sum over the rows r of segment s, in order, of y[r][c] * pool_att[r])
-    //                  * pool_gate[s]     (no gate factor when pool_gate == null)
-    // with s = dot_seg[r]; rows are grouped by segment, segments ascending.
-    // POOL == 2 (pool_groups > 1 groups of cout / pool_groups channels, a multiple of 4):
-    // pool_att is [rows][pool_groups] and already carries the gate factor.
+    // pool_out[s][c] = sum over the rows r of segment s, in order, of y[r][c] * pool_att[r][group(c)]
+    // with s = dot_seg[r]; rows are grouped by segment, segments ascending.  pool_att is
+    // [rows][pool_groups] and already carries the gate factor of the row's segment (a
+    // per-segment factor read at every segment change would be a dependent load in the
+    // epilogue).  POOL == 2: pool_groups > 1 groups of cout / pool_groups channels.
     const float *pool_att;
-    const float *pool_gate;
     float *pool_out;
     int pool_groups;
 };
@@ -364,7 +363,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         // after the first layer; the segments of the rows next to the wave's tile tell
         // whether its first / last segment continues in a neighbouring tile
         int pseg = -1, pprev = -1, pnext = -1;
-        float patt = 0.f, pgate = 1.f;
+        float patt = 0.f;
         // POOL == 2: the [32][groups] attention weights of the wave's rows are contiguous in
         // memory; they are fetched here with coalesced loads, parked in the (idle) staging rows
         // after the first layer and picked up per lane right before the epilogue
@@ -442,14 +441,18 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], xr[4 * g + e], acc0, 0, 0, 0);
                     }
             }
-            if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, S);
         }
-        if (POOL == 1 && A.pool_gate && live) pgate = A.pool_gate[pseg];
-        if (POOL == 2) {
-            float *stg_att = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
+        if (POOL) {
+            // The pool's per-row loads of this tile are waited for here, before the next
+            // tile's rows are requested: that request is conditional, so any later wait for
+            // a load older than it would have to wait for it as well.
+            if (POOL == 2) {
+                float *stg_att = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
 #pragma unroll
-            for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k)
-                if (lane + 64 * k < 32 * A.pool_groups) stg_att[lane + 64 * k] = pa[k];
+                for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k)
+                    if (lane + 64 * k < 32 * A.pool_groups) stg_att[lane + 64 * k] = pa[k];
+            }
+            asm volatile("" : "+v"(pseg), "+v"(patt), "+v"(pprev), "+v"(pnext) : : "memory");
         }
         if (A.dot_out) {
             const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
@@ -463,6 +466,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                 qv[4 * g] = t.x; qv[4 * g + 1] = t.y; qv[4 * g + 2] = t.z; qv[4 * g + 3] = t.w;
             }
         }
+        // The next tile's rows, requested behind every load of this tile that depends on an
+        // earlier one (the request is conditional: a later wait for an older load would wait
+        // for it too).  (prefetch implies a single chunk, whose steps are S = (cin0 + 1) / 2)
+        if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, (cin0 + 1) >> 1);
         // ---- the following layers, activations stay in registers ----
         auto nothing = [](int) {};
 #pragma unroll
@@ -584,9 +591,8 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             int cur = __builtin_amdgcn_readlane(pseg, 0);
             bool partial = cur == pprev;                 // the current segment began before this tile
             float accv = 0.f;
-            auto flush = [&](int seg, float v, bool part, float gate_) {
+            auto flush = [&](int seg, float v, bool part) {
                 if (seg < 0 || lane >= cout) return;
-                if (POOL == 1 && A.pool_gate) v = __fmul_rn(v, gate_);
                 float *o = A.pool_out + (size_t)seg * cout + lane;
                 if (part) unsafeAtomicAdd(o, v);
                 else *o = v;
@@ -615,8 +621,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                     const int r = half * POOL_STAGE_ROWS + i;
                     const int s = __builtin_amdgcn_readlane(pseg, r);
                     if (s != cur) {
-                        // r >= 1 here: row 0 defines cur
-                        flush(cur, accv, partial, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pgate), r > 0 ? r - 1 : 0)));
+                        flush(cur, accv, partial);
                         partial = false;
                         cur = s;
                         accv = 0.f;
@@ -629,7 +634,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             }
             // rows past the end carry segment -1: a tile that holds some has flushed its
             // last segment at the change and ends with cur = -1
-            flush(cur, accv, partial || cur == pnext, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pgate), 31)));
+            flush(cur, accv, partial || cur == pnext);
         }
     tile_done:;
     }
@@ -704,8 +709,8 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
 {
     // pool_out != null: the launch prepares the pool epilogue of the layer chain.  The
     // rows of empty segments and of segments that cross a tile boundary start from zero
-    // (thread (s, g) clears the channels of group g), and with more than one group the
-    // gate is folded into the attention weights.
+    // (thread (s, g) clears the channels of group g), and the gate is folded into the
+    // attention weights.
     const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
     if (t >= nseg * G) return;
     const i64 s = t / G;
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         fold = tanhf(x > 0.f ? x : 0.f);
         gate[t] = fold;
     }
-    if (!(pool_out && G > 1 && gate)) fold = 1.f;
+    if (!(pool_out && gate)) fold = 1.f;
     if (b <= a) return;
     const float sq = sqrtf((float)(b - a));
     float sum = 0.f;
@@ -897,8 +902,7 @@ static int mlp_forward_impl(
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
     float dot_div, float *dot_out, void *stream,
-    const float *pool_att = nullptr, const float *pool_gate = nullptr, float *pool_out = nullptr,
-    int32_t pool_groups = 1)
+    const float *pool_att = nullptr, float *pool_out = nullptr, int32_t pool_groups = 1)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
@@ -910,8 +914,8 @@ static int mlp_forward_impl(
         const int co = layers[nlayers - 1].cout;
         static_assert(32 * POOL_MAX_GROUPS <= POOL_STAGE_ROWS * POOL_PITCH, "the weights of a tile are parked in its staging rows");
         MVF_REQUIRE(pool_groups >= 1 && pool_groups <= POOL_MAX_GROUPS &&
-                    (pool_groups == 1 || (!pool_gate && co % pool_groups == 0 && (co / pool_groups) % 4 == 0)),
-                    "mlp_forward_pool: %d groups; at most 8 equal groups of a multiple of 4 channels, the gate folded into att", pool_groups);
+                    (pool_groups == 1 || (co % pool_groups == 0 && (co / pool_groups) % 4 == 0)),
+                    "mlp_forward_pool: %d groups; at most 8 equal groups of a multiple of 4 channels", pool_groups);
         out = pool_out; ldo = layers[nlayers - 1].cout;                 // never written through `out`
     }
     if (dot_out) {
@@ -949,7 +953,7 @@ static int mlp_forward_impl(
     A.out = out;
     A.ldo = ldo;
     A.dot_q = dot_q; A.dot_seg = dot_seg; A.dot_ldq = dot_ldq; A.dot_div = dot_div; A.dot_out = dot_out;
-    A.pool_att = pool_att; A.pool_gate = pool_gate; A.pool_out = pool_out; A.pool_groups = pool_groups;
+    A.pool_att = pool_att; A.pool_out = pool_out; A.pool_groups = pool_groups;
     if (pool_out) A.dot_seg = dot_seg;
     A.debug = 0;
 #ifdef MVF_MLP_DEBUG
@@ -1052,11 +1056,11 @@ extern "C" int mvf_mlp_forward_pool(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    const float *att, int32_t G, const int32_t *row2seg, const float *gate, float *pool_out, void *stream)
+    const float *att, int32_t G, const int32_t *row2seg, float *pool_out, void *stream)
 {
     MVF_REQUIRE(pool_out, "mlp_forward_pool: null output");
     return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
-                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, gate, pool_out, G);
+                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, pool_out, G);
 }
 
 extern "C" int mvf_attention_pool(

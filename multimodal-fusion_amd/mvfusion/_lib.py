@@ -96,7 +96,7 @@ _SIGNATURES = {
     "mvf_mlp_forward_dot": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _I64, _P, _I32,
                                       _P, _I32, _P, _F, _P, _P]),
     "mvf_mlp_forward_pool": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I64, _P, _I32,
-                                       _P, _I32, _P, _P, _P, _P]),
+                                       _P, _I32, _P, _P, _P]),
     "mvf_attention_pool": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32,
                                      _I32, _I32, _I32, _F, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "mvf_csr_row_segments": (C.c_int, [_P, _I64, _P, _P]),

@@ -91,7 +91,7 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     of (LayerSpec, lo, hi); out = tensor view whose first element is the
     output's first column, ldo_tensor = row stride in floats.  dot = (queries,
     row2seg, divisor): mvf_mlp_forward_dot, `out` is the [rows] dot output.
-    pool = (att, row2seg, gate): mvf_mlp_forward_pool, `out` is the prepared
+    pool = (att, row2seg): mvf_mlp_forward_pool, `out` is the prepared
     [nseg, cout] pool output."""
     lib = L.load()
     xa, ga, xb, gb, mode = src
@@ -114,12 +114,12 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     dev = xa.device
     with torch.cuda.device(dev):
         if pool is not None:
-            att, seg, gate = pool
+            att, seg = pool
             L.check(lib.mvf_mlp_forward_pool(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
                 L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
                 L.ptr(gb), rows, arr, len(specs), L.ptr(att), att.shape[1], L.ptr(seg),
-                L.ptr(gate if att.shape[1] == 1 else None), L.ptr(out), L.stream_ptr(dev)))
+                L.ptr(out), L.stream_ptr(dev)))
         elif dot is None:
             L.check(lib.mvf_mlp_forward(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
@@ -221,13 +221,12 @@ def pool_fusable(specs, x, num_groups):
             and x.shape[0] > 0)
 
 
-def pooled_layers(specs, x, att, row2seg, gate, out):
-    """out[s] = (sum_{r in s} specs(x)[r] * att[r]) * gate[s]: the layer chain with
-    the pool epilogue (needs pool_fusable; `att` [rows, G], `gate` and `out` as
-    returned by attention_pool(<number of channels>, ...): with more than one
-    group that `att` already carries the gate)."""
+def pooled_layers(specs, x, att, row2seg, out):
+    """out[s] = sum_{r in s} specs(x)[r] * att[r]: the layer chain with the pool
+    epilogue (needs pool_fusable; `att` [rows, G] and `out` as returned by
+    attention_pool(<number of channels>, ...): that `att` carries the gate)."""
     _launch((x.detach(), None, None, None, 0), [(sp, 0, sp.cout) for sp in specs], None, out,
-            specs[-1].cout, pool=(att, row2seg, gate))
+            specs[-1].cout, pool=(att, row2seg))
     return out
 
 
@@ -249,8 +248,7 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
     ``comp`` (the compatibilities) is given; ``row2seg`` maps key rows to query
     rows (None: one query row per key row).  ``x_mod`` may be the number of
     value channels instead of the values: the scores are computed and x_pool
-    comes back prepared for pooled_layers() (with more than one group ``att``
-    then holds att * gate)."""
+    comes back prepared for pooled_layers() (``att`` then holds att * gate)."""
     lib = L.load()
     if isinstance(x_mod, int):
         src = keys if keys is not None else comp

@@ -226,11 +226,11 @@ def test_mlp_chain_dot_epilogue():
 def test_mlp_chain_pool_epilogue(C, gating, G):
     """The value encoder with the attention-weighted segment sum as epilogue
     against encoder launch + attention_pool on the same compatibilities:
-    identical bits for every segment inside one 32-row tile, 1e-6 of the output
+    identical bits (without a gate) for every segment inside one 32-row tile, 1e-6 of the output
     scale for the segments that cross a tile boundary; empty segments, segments of
-    more than 64 rows (three tiles) and a ragged last tile included.  With more
-    than one group the gate is folded into the attention weights, so every
-    segment is compared at 1e-6.  Then the two modules that use it, with and
+    more than 64 rows (three tiles) and a ragged last tile included.  A gate is
+    folded into the attention weights, so with one every segment is compared at
+    1e-6.  Then the two modules that use it, with and
     without save_last (which keeps the unfused launches)."""
     from mvfusion import dense
     rng = np.random.default_rng(11)
@@ -258,11 +258,11 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
     def fused_pass():
         out, _, att2, gate2 = dense.attention_pool(C, dptr, G, c2g, **kw)
         assert gate is None or torch.equal(gate2, gate)
-        if G == 1 or gate is None:
+        if gate is None:
             assert torch.equal(att2, att)
         else:
             assert torch.equal(att2, att * gate[row2seg.long()])
-        return dense.pooled_layers(specs, x_mod, att2, row2seg, gate2, out)
+        return dense.pooled_layers(specs, x_mod, att2, row2seg, out)
 
     fused, again = fused_pass(), fused_pass()
     assert fused.shape == plain.shape == (N, C) and float(plain.abs().max()) > 0.01
@@ -270,7 +270,7 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
     two_tiles = (ptr[:-1] // 32 + 1 == (ptr[1:] - 1) // 32)
     assert inside.sum() > 0.8 * N and (~inside).sum() > 100
     m = torch.from_numpy(inside).to(DEV)
-    if G == 1 or not gating:
+    if not gating:
         assert torch.equal(fused[m], plain[m])
     _close(fused, plain.cpu().numpy(), rtol=1e-6)
     assert float(fused[T(counts == 0)].abs().max()) == 0.0
