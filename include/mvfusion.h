@@ -337,7 +337,7 @@ int mvf_mlp_forward_dot(
     void *stream);
 
 /* The same chain (two layers of equal output width <= 64: E_mod, pooling.py:757,
- * 482-484; mode 0 inputs, 16-byte aligned) with the attention-weighted segment
+ * 482-484; mode 0 inputs without row gathers, 16-byte aligned) with the attention-weighted segment
  * sum as epilogue: the encoded view features are not stored; instead
  *   pool_out[s][c] = sum over the rows r of segment s of y[r][c] * att[r][group(c)]
  * i.e. pooling.py:519-530 / :295-300 without the [rows][cout] values leaving

@@ -331,17 +331,36 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     float xr[32];
     // The lane's half of a 64-column chunk of its row, 16-byte loads.  Rows past
     // the end read row 0; their results are never stored.
-    auto load_rows = [&](i64 base_, int k0, int S) {
+    // Source rows of the lane's row of the tile at base_ (row gathers applied).  Rows past
+    // the end read row 0; their results are never stored.
+    // (the pool kernels take ungathered rows only: the host checks)
+    auto gather_rows = [&](i64 base_, int &ga, int &gb) {
         const i64 row_ = base_ + wave * 32 + jrow;
         const bool live_ = row_ < A.rows;
-        i64 ra = live_ ? row_ : 0, rb = ra;
-        if (live_ && A.a.gather) ra = A.a.gather[row_];
-        if (live_ && A.b.gather) rb = A.b.gather[row_];
+        ga = gb = 0;
+        if (!POOL && live_ && A.a.gather) ga = A.a.gather[row_];
+        if (!POOL && live_ && A.b.gather) gb = A.b.gather[row_];
+    };
+    auto source_rows = [&](i64 base_, int ga, int gb, i64 &ra, i64 &rb) {
+        const i64 row_ = base_ + wave * 32 + jrow;
+        ra = rb = row_ < A.rows ? row_ : 0;
+        if (!POOL && A.a.gather) ra = ga;
+        if (!POOL && A.b.gather) rb = gb;
+    };
+    // The lane's half of a 64-column chunk of its row, 16-byte loads.
+    auto load_rows_at = [&](i64 ra, i64 rb, int k0, int S) {
         const float *pa = A.a.p + ra * A.a.ld;
         const float *pb = A.b.p ? A.b.p + rb * A.b.ld : pa;
         if (mode == 0) mlp_load_row<0>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
         else if (mode == 1) mlp_load_row<1>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
         else mlp_load_row<2>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+    };
+    auto load_rows = [&](i64 base_, int k0, int S) {
+        int ga, gb;
+        i64 ra, rb;
+        gather_rows(base_, ga, gb);
+        source_rows(base_, ga, gb, ra, rb);
+        load_rows_at(ra, rb, k0, S);
     };
     // With a single chunk the next tile's rows are requested right after the
     // first layer has consumed the current ones, so their latency hides behind
@@ -349,6 +368,12 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     const bool prefetch = vec_in && nchunks == 1;
     const i64 stride = (i64)gridDim.x * MLP_ROWS;
     if (prefetch && (i64)blockIdx.x * MLP_ROWS < A.rows) load_rows((i64)blockIdx.x * MLP_ROWS, 0, (cin0 + 1) >> 1);
+    // With row gathers the rows of a tile hang on its gather indices: those are fetched one
+    // tile further ahead (nga / ngb: gather indices of the tile after the current one), so
+    // the request for the rows never waits for them.
+    const bool gathered = !POOL && prefetch && (A.a.gather || A.b.gather);
+    int nga = 0, ngb = 0;
+    if (gathered && (i64)blockIdx.x * MLP_ROWS + stride < A.rows) gather_rows((i64)blockIdx.x * MLP_ROWS + stride, nga, ngb);
     for (i64 base = (i64)blockIdx.x * MLP_ROWS; base < A.rows; base += stride) {
         const i64 row = base + wave * 32 + jrow;
         const bool live = row < A.rows;
@@ -469,7 +494,16 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         // The next tile's rows, requested behind every load of this tile that depends on an
         // earlier one (the request is conditional: a later wait for an older load would wait
         // for it too).  (prefetch implies a single chunk, whose steps are S = (cin0 + 1) / 2)
-        if (prefetch && base + stride < A.rows) load_rows(base + stride, 0, (cin0 + 1) >> 1);
+        if (prefetch && base + stride < A.rows) {
+            if (gathered) {
+                i64 ra, rb;
+                source_rows(base + stride, nga, ngb, ra, rb);
+                load_rows_at(ra, rb, 0, (cin0 + 1) >> 1);
+                if (base + 2 * stride < A.rows) gather_rows(base + 2 * stride, nga, ngb);
+            } else {
+                load_rows(base + stride, 0, (cin0 + 1) >> 1);
+            }
+        }
         // ---- the following layers, activations stay in registers ----
         auto nothing = [](int) {};
 #pragma unroll
@@ -911,6 +945,7 @@ static int mlp_forward_impl(
     MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out || pool_out), "mlp_forward: bad first input");
     if (pool_out) {
         MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
+        MVF_REQUIRE(!gather_a && !gather_b, "mlp_forward_pool: row gathers are not supported");
         const int co = layers[nlayers - 1].cout;
         static_assert(32 * POOL_MAX_GROUPS <= POOL_STAGE_ROWS * POOL_PITCH, "the weights of a tile are parked in its staging rows");
         MVF_REQUIRE(pool_groups >= 1 && pool_groups <= POOL_MAX_GROUPS &&
