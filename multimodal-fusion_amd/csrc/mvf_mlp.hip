@@ -384,9 +384,9 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         // layer, so that neither load is waited for at the end of the tile
         const int qseg = (A.dot_out && live) ? A.dot_seg[row] : 0;
         float qv[16];
-        // pool epilogue: the row's segment and attention weight now, the segment's gate
-        // after the first layer; the segments of the rows next to the wave's tile tell
-        // whether its first / last segment continues in a neighbouring tile
+        // pool epilogue: the row's segment and attention weight now; the segments of the rows
+        // next to the wave's tile tell whether its first / last segment continues in a
+        // neighbouring tile
         int pseg = -1, pprev = -1, pnext = -1;
         float patt = 0.f;
         // POOL == 2: the [32][groups] attention weights of the wave's rows are contiguous in
