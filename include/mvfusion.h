@@ -371,8 +371,8 @@ int mvf_mlp_forward_pool(
  * may keep (the modules' save_last tensors).  chan2group may be NULL when G == 1.
  * x_mod == NULL with rows > 0: comp, att and gate are computed and `out` [nseg][C]
  * is prepared for mvf_mlp_forward_pool, which then produces the sum; att comes
- * back times the gate of its segment (G > 1 needs G <= 8, C % G == 0 and
- * (C / G) % 4 == 0). */
+ * back times the gate of its segment (needs G <= 8, C % G == 0, (C / G) % 4 == 0
+ * and a 16-byte aligned `out`). */
 int mvf_attention_pool(
     const float *keys, int32_t ldk, const float *queries, int32_t ldq, const int32_t *row2seg,
     const float *x_mod, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows, int32_t G, int32_t D,

@@ -750,16 +750,30 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
     const i64 s = t / G;
     const int g = (int)(t - s * G);
     const i64 a = ptr[s], b = ptr[s + 1];
-        if (pool_out && (b <= a || a / POOL_TILE != (b - 1) / POOL_TILE)) {
+    if (pool_out && (b <= a || a / POOL_TILE != (b - 1) / POOL_TILE)) {
+        // (a multiple of 4 channels per group and a 16-byte aligned output: the host checks)
         const int cg = pool_C / G;
-        float *o = pool_out + (size_t)s * pool_C + (size_t)g * cg;
-        for (int c = 0; c < cg; ++c) o[c] = 0.f;
+        float4 *o = (float4 *)(pool_out + (size_t)s * pool_C + (size_t)g * cg);
+        for (int c = 0; c < cg / 4; ++c) o[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float fold = 1.f;
     float mx = 0.f;                                    // segment max of nothing is 0
-    for (i64 r = a; r < b; ++r) {
-        const float c = comp[(size_t)r * G + g];
-        mx = (r == a || c > mx) ? c : mx;
+    // Segments of at most SHORT rows (most of them: a point is seen in a handful of views)
+    // keep their compatibilities in registers: one round of loads, all in flight together.
+    constexpr int SHORT = 8;
+    const i64 n = b - a;
+    float cs[SHORT];
+    if (n <= SHORT) {
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i) cs[i] = i < n ? comp[(size_t)(a + i) * G + g] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i)
+            if (i < n) mx = (i == 0 || cs[i] > mx) ? cs[i] : mx;
+    } else {
+        for (i64 r = a; r < b; ++r) {
+            const float c = comp[(size_t)r * G + g];
+            mx = (r == a || c > mx) ? c : mx;
+        }
     }
     if (gate) {
         float x = mx;
@@ -768,10 +782,25 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         fold = tanhf(x > 0.f ? x : 0.f);
         gate[t] = fold;
     }
-    if (!(pool_out && gate)) fold = 1.f;
-    if (b <= a) return;
-    const float sq = sqrtf((float)(b - a));
+    if (!(pool_out && gate)) fold = 1.f;               // times 1 is exact
+    if (n <= 0) return;
+    const float sq = sqrtf((float)n);
     float sum = 0.f;
+    if (n <= SHORT) {
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i)
+            if (i < n) {
+                float c = __fsub_rn(cs[i], mx);
+                if (group_scaling) c = __fdiv_rn(c, sq);
+                cs[i] = expf(c);
+                sum = i == 0 ? cs[i] : __fadd_rn(sum, cs[i]);
+            }
+        sum = __fadd_rn(sum, eps);
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i)
+            if (i < n) att[(size_t)(a + i) * G + g] = __fmul_rn(__fdiv_rn(cs[i], sum), fold);
+        return;
+    }
     for (i64 r = a; r < b; ++r) {
         float c = __fsub_rn(comp[(size_t)r * G + g], mx);
         if (group_scaling) c = __fdiv_rn(c, sq);
@@ -780,12 +809,8 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         sum = (r == a) ? e : __fadd_rn(sum, e);
     }
     sum = __fadd_rn(sum, eps);
-    if (fold == 1.f) {
-        for (i64 r = a; r < b; ++r) att[(size_t)r * G + g] = __fdiv_rn(att[(size_t)r * G + g], sum);
-    } else {
-        for (i64 r = a; r < b; ++r)
-            att[(size_t)r * G + g] = __fmul_rn(__fdiv_rn(att[(size_t)r * G + g], sum), fold);
-    }
+    for (i64 r = a; r < b; ++r)
+        att[(size_t)r * G + g] = __fmul_rn(__fdiv_rn(att[(size_t)r * G + g], sum), fold);
 }
 
 // x_pool[s][c] = (sum_r x[r][c] * att[r][group(c)]) * gate[s][group(c)], rows
@@ -1114,8 +1139,8 @@ extern "C" int mvf_attention_pool(
     MVF_REQUIRE(ptr && out && (rows == 0 || (comp && att)), "attention_pool: null buffer");
     // x_mod == NULL: scores only; `out` is prepared for mvf_mlp_forward_pool
     const bool prepare = x_mod == nullptr && rows > 0;
-    MVF_REQUIRE(!prepare || G == 1 || (G <= POOL_MAX_GROUPS && C % G == 0 && (C / G) % 4 == 0),
-                "attention_pool: the fused pool needs at most 8 equal groups of a multiple of 4 channels");
+    MVF_REQUIRE(!prepare || (G <= POOL_MAX_GROUPS && C % G == 0 && (C / G) % 4 == 0 && (uintptr_t)out % 16 == 0),
+                "attention_pool: the fused pool needs at most 8 equal groups of a multiple of 4 channels and a 16-byte aligned output");
     hipStream_t st = (hipStream_t)stream;
     if (keys && rows > 0) {
         const float dim_div = dim_scaling ? (float)sqrt((double)D) : 0.f;
