@@ -357,6 +357,20 @@ int mvf_mlp_forward_pool(
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     const float *att, int32_t G, const int32_t *row2seg, float *pool_out, void *stream);
 
+/* The same chain (two layers of equal output width <= 64: DeepSetFeat.mlp_elt_1,
+ * pooling.py:633; mode 0 inputs without row gathers, 16-byte aligned rows in and
+ * out) that stores its rows AND their per-segment maximum,
+ *   seg_out[s][c] = max over the rows r of segment s of out[r][c]     (0 for an empty segment)
+ * i.e. segment_csr(mlp_elt_1(x), csr_idx, reduce='max') of pooling.py:628-633
+ * without reading the rows back.  ptr [nseg + 1] and row2seg [rows] describe the
+ * same segments.  Bit-identical to mvf_mlp_forward followed by mvf_segment_csr
+ * (segments crossing a 32-row tile are combined with atomic maxima, which do
+ * not depend on order). */
+int mvf_mlp_forward_segmax(
+    const float *xa, int32_t lda, int32_t cols_a, const float *xb, int32_t ldb, int32_t cols_b,
+    int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers, float *out, int32_t ldo,
+    const int64_t *ptr, int64_t nseg, const int32_t *row2seg, float *seg_out, void *stream);
+
 /* The attention tail shared by QKVBimodalCSRPool.forward (pooling.py:503-530)
  * and GroupBimodalCSRPool.forward (pooling.py:284-300):
  *   comp[r][g] = sum_k keys[r][g D + k] * queries[seg(r)][g D + k]   (/ sqrt(D) if dim_scaling)

@@ -261,6 +261,15 @@ __device__ __forceinline__ void mlp_store(
     }
 }
 
+// max(*p, v) on a float in global memory without a compare-and-swap loop: non-negative
+// floats order like signed integers, negative ones like unsigned integers reversed
+// (-inf, the preset of the pool epilogue, is below every value in both views).
+__device__ __forceinline__ void atomic_max_float(float *p, float v)
+{
+    if (v >= 0.f) atomicMax((int *)p, __float_as_int(v));
+    else atomicMin((unsigned *)p, __float_as_uint(v));
+}
+
 // NL / WMASK >= 0 fix the number of layers and which of them are wider than 32
 // outputs (bit l of WMASK) at compile time, for the aligned single-source or
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
@@ -528,7 +537,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                     if ((step + 1) % per == 0) {
                         const int g = step / per;
                         mlp_epilogue4(n0, g, L2);
-                        if (!POOL && live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
+                        if ((POOL == 0 || POOL == 3) && live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
                     }
                 };
                 mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A));
@@ -536,7 +545,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     mlp_epilogue4(n1, g, L2);
-                    if (!POOL && live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
+                    if ((POOL == 0 || POOL == 3) && live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
                 }
                 acc0 = n0; acc1 = n1;
                 if (POOL) goto pool_tail;
@@ -571,13 +580,13 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 mlp_epilogue4(acc0, g, L);
-                if (!POOL && live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
+                if ((POOL == 0 || POOL == 3) && live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
             }
             if (wide) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     mlp_epilogue4(acc1, g, L);
-                    if (!POOL && live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
+                    if ((POOL == 0 || POOL == 3) && live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
                 }
             }
         }
@@ -615,7 +624,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else {
+            } else if (POOL == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc0[r] = __fmul_rn(acc0[r], patt);
@@ -624,12 +633,16 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             }
             int cur = __builtin_amdgcn_readlane(pseg, 0);
             bool partial = cur == pprev;                 // the current segment began before this tile
-            float accv = 0.f;
+            // POOL == 3 folds with max instead of a sum (first row wins ties, as in the
+            // segment kernels); a partial maximum meets the others in a row preset to -inf
+            constexpr float FOLD0 = POOL == 3 ? -INFINITY : 0.f;
+            float accv = FOLD0;
             auto flush = [&](int seg, float v, bool part) {
                 if (seg < 0 || lane >= cout) return;
                 float *o = A.pool_out + (size_t)seg * cout + lane;
-                if (part) unsafeAtomicAdd(o, v);
-                else *o = v;
+                if (!part) *o = v;
+                else if (POOL == 3) atomic_max_float(o, v);
+                else unsafeAtomicAdd(o, v);
             };
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
@@ -658,9 +671,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                         flush(cur, accv, partial);
                         partial = false;
                         cur = s;
-                        accv = 0.f;
+                        accv = FOLD0;
                     }
-                    accv = __fadd_rn(accv, v[i]);
+                    if (POOL == 3) accv = v[i] > accv ? v[i] : accv;
+                    else accv = __fadd_rn(accv, v[i]);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -936,6 +950,21 @@ __global__ __launch_bounds__(256) void segment_pick_kernel(
     out[e] = v;
 }
 
+// Ahead of the max-pool epilogue: rows of empty segments are 0 (the pools' value of an empty
+// segment), rows of segments that cross a 32-row tile start from -inf; every other row is
+// stored by the epilogue itself.
+__global__ __launch_bounds__(256) void segmax_prepare_kernel(
+    const i64 *__restrict__ ptr, i64 nseg, float *__restrict__ out, int C)
+{
+    const i64 s = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (s >= nseg) return;
+    const i64 a = ptr[s], b = ptr[s + 1];
+    if (b > a && a / POOL_TILE == (b - 1) / POOL_TILE) return;
+    const float v = b > a ? -INFINITY : 0.f;
+    float4 *o = (float4 *)(out + (size_t)s * C);
+    for (int c = 0; c < C / 4; ++c) o[c] = make_float4(v, v, v, v);
+}
+
 static size_t mlp_lds_bytes(const mvf_mlp_layer *L, int n)
 {
     size_t f = 2 * MLP_MAX_LAYERS * MLP_MAX_C;
@@ -961,14 +990,18 @@ static int mlp_forward_impl(
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
     float dot_div, float *dot_out, void *stream,
-    const float *pool_att = nullptr, float *pool_out = nullptr, int32_t pool_groups = 1)
+    const float *pool_att = nullptr, float *pool_out = nullptr, int32_t pool_groups = 1,
+    bool pool_max = false)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
     MVF_REQUIRE(mode >= 0 && mode <= 2, "mlp_forward: unknown input mode %d", mode);
     if (rows == 0) return MVF_OK;
     MVF_REQUIRE(xa && cols_a >= 1 && lda >= cols_a && (out || dot_out || pool_out), "mlp_forward: bad first input");
-    if (pool_out) {
+    if (pool_out && pool_max) {
+        MVF_REQUIRE(dot_seg && !dot_out && out && !gather_a && !gather_b,
+                    "mlp_forward_segmax: needs the row output and the row -> segment map, no row gathers");
+    } else if (pool_out) {
         MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
         MVF_REQUIRE(!gather_a && !gather_b, "mlp_forward_pool: row gathers are not supported");
         const int co = layers[nlayers - 1].cout;
@@ -1023,7 +1056,7 @@ static int mlp_forward_impl(
     const bool al_a = ((uintptr_t)xa % 16 == 0) && lda % 4 == 0;
     const bool al_b = !xb || (((uintptr_t)xb % 16 == 0) && ldb % 4 == 0);
     A.vec_in = al_a && al_b && cin0 % 8 == 0 && cols_a % 4 == 0;
-    A.vec_out = dot_out || pool_out || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
+    A.vec_out = dot_out || (pool_out && !pool_max) || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
     const size_t lds = mlp_lds_bytes(layers, nlayers) +
                        (pool_out ? sizeof(float) * MLP_WAVES * POOL_STAGE_ROWS * POOL_PITCH : 0);
     static int cus = 0;
@@ -1060,7 +1093,10 @@ static int mlp_forward_impl(
     if (pool_out) {
         MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
                     "mlp_forward_pool: two layers of equal output width on 16-byte aligned, unsummed inputs only");
-        if (pool_groups == 1) {
+        if (pool_max) {
+            if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0, 3);
+            else MVF_MLP_LAUNCH_POOL(2, 3, 3);
+        } else if (pool_groups == 1) {
             if (wmask == 0) MVF_MLP_LAUNCH_POOL(2, 0, 1);
             else MVF_MLP_LAUNCH_POOL(2, 3, 1);
         } else {
@@ -1121,6 +1157,22 @@ extern "C" int mvf_mlp_forward_pool(
     MVF_REQUIRE(pool_out, "mlp_forward_pool: null output");
     return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
                             nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, pool_out, G);
+}
+
+extern "C" int mvf_mlp_forward_segmax(
+    const float *xa, int32_t lda, int32_t cols_a, const float *xb, int32_t ldb, int32_t cols_b,
+    int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers, float *out, int32_t ldo,
+    const int64_t *ptr, int64_t nseg, const int32_t *row2seg, float *seg_out, void *stream)
+{
+    MVF_REQUIRE(nseg >= 0 && rows >= 0 && layers && nlayers >= 1, "mlp_forward_segmax: bad shape");
+    if (nseg == 0) return MVF_OK;
+    MVF_REQUIRE(ptr && seg_out && (uintptr_t)seg_out % 16 == 0 && layers[nlayers - 1].cout % 4 == 0,
+                "mlp_forward_segmax: needs the pointers and a 16-byte aligned segment output of a multiple of 4 channels");
+    hipLaunchKernelGGL(segmax_prepare_kernel, dim3(cdiv(nseg, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const i64 *)ptr, (i64)nseg, seg_out, layers[nlayers - 1].cout);
+    MVF_LAUNCH_CHECK();
+    return mlp_forward_impl(xa, lda, cols_a, nullptr, xb, ldb, cols_b, nullptr, 0, rows, layers,
+                            nlayers, out, ldo, nullptr, 0, row2seg, 0.f, nullptr, stream, nullptr, seg_out, 1, true);
 }
 
 extern "C" int mvf_attention_pool(

@@ -230,6 +230,39 @@ def pooled_layers(specs, x, att, row2seg, out):
     return out
 
 
+def layers_with_segment_max(specs, x, ptr, row2seg):
+    """(y, segment max of y) with y = specs(x): the layer chain stores its rows and
+    folds their per-segment maximum in the same launch (needs pool_fusable(specs,
+    x, 1)); equals (run_layers(specs, x), segment_csr(y, ptr, 'max')) bit for bit."""
+    lib = L.load()
+    x = x.detach()
+    rows, cout = x.shape[0], specs[-1].cout
+    nseg = ptr.shape[0] - 1
+    keep = []
+    arr = (L.MvfMlpLayer * len(specs))()
+    for i, sp in enumerate(specs):
+        _check_eval(sp)
+        w, b, bw, bb, bm, bv = sp.tensors()
+        keep += [w, b, bw, bb, bm, bv]
+        a = arr[i]
+        a.weight, a.bias = w.data_ptr(), (b.data_ptr() if b is not None else None)
+        a.bn_weight = bw.data_ptr() if bw is not None else None
+        a.bn_bias = bb.data_ptr() if bb is not None else None
+        a.bn_mean = bm.data_ptr() if bm is not None else None
+        a.bn_var = bv.data_ptr() if bv is not None else None
+        a.bn_eps = float(sp.bn.eps) if sp.bn is not None else 0.0
+        a.slope = float(sp.slope) if sp.slope is not None else 0.0
+        a.cin, a.cout, a.act = sp.cin, sp.cout, int(sp.slope is not None)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    seg = torch.empty((nseg, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(lib.mvf_mlp_forward_segmax(
+            L.ptr(x), x.stride(0), x.shape[1], None, 0, 0, rows, arr, len(specs),
+            L.ptr(out), cout, L.ptr(ptr), nseg, L.ptr(row2seg), L.ptr(seg), L.stream_ptr(x.device)))
+    del keep
+    return out, seg
+
+
 def csr_row_segments(ptr, rows):
     """int32 [rows]: segment index of every row of a CSR pointer array."""
     lib = L.load()

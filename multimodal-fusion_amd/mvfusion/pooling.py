@@ -521,8 +521,14 @@ class DeepSetFeat(nn.Module, ABC):
         row per element (run_layers' dot)."""
         if row2seg is None:
             row2seg = _dense.csr_row_segments(ptr, x.shape[0])
-        x1 = _dense.run_layers(_dense.mlp_layers(self.mlp_elt_1), x)
-        sets = [segment_csr(x1, ptr, reduce=p) for p in self.pool]
+        elt_1 = _dense.mlp_layers(self.mlp_elt_1)
+        if self.pool == ['max'] and _dense.pool_fusable(elt_1, x, 1):
+            # the rows and their per-segment maximum out of one launch
+            x1, x_max = _dense.layers_with_segment_max(elt_1, x, ptr, row2seg)
+            sets = [x_max]
+        else:
+            x1 = _dense.run_layers(elt_1, x)
+            sets = [segment_csr(x1, ptr, reduce=p) for p in self.pool]
         if self.use_num:
             sets.append(_set_num(ptr).view(-1, 1))
         x_set = torch.cat(sets, dim=-1) if len(sets) > 1 else sets[0]

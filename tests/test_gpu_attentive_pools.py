@@ -292,3 +292,32 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
         b = mod(*args)
         assert float(b.abs().max()) > 0.01
         _close(a, b.cpu().numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("cin,C", [(8, 32), (16, 64), (8, 8)])
+def test_mlp_chain_segment_max_epilogue(cin, C):
+    """Layer chain that stores its rows and their per-segment maximum in one
+    launch against run_layers + segment_csr: identical bits, empty segments,
+    segments over several 32-row tiles and a ragged last tile included."""
+    from mvfusion import dense
+    from mvfusion.pooling import segment_csr
+    rng = np.random.default_rng(13)
+    N = 20011
+    counts = np.minimum(rng.poisson(4, N), 32)
+    counts[rng.random(N) < 0.05] = 0
+    counts[[0, 17, 5000, N - 1]] = [0, 70, 131, 45]
+    ptr = T(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64))
+    Vw = int(ptr[-1])
+    x = T((rng.random((Vw, cin)) - 0.5).astype(np.float32))
+    torch.manual_seed(C)
+    mlp = _random_module(pooling.MLP([cin, C, C], bias=False), 3).to(DEV).eval()
+    specs = dense.mlp_layers(mlp)
+    assert dense.pool_fusable(specs, x, 1)
+    row2seg = dense.csr_row_segments(ptr, Vw)
+    rows, smax = dense.layers_with_segment_max(specs, x, ptr, row2seg)
+    want_rows = dense.run_layers(specs, x)
+    want_max = segment_csr(want_rows, ptr, reduce="max")
+    assert (want_max < 0).any() and (want_max > 0).any()
+    assert torch.equal(rows, want_rows)
+    assert torch.equal(smax, want_max)
+    assert float(smax[T(counts == 0)].abs().max()) == 0.0
