@@ -406,3 +406,55 @@ def test_view_sharded_attentive_pool_equals_single_pass():
     # single process: the exchange is the identity
     one = D.view_sharded_attentive_pool(pool, x_main, xv, xm, ptr)
     assert torch.equal(one, pool(x_main, xv, xm, ptr)) or torch.allclose(one, want, rtol=1e-6, atol=1e-6 * scale)
+
+
+def test_c3_qkv_pool_full_size():
+    """C3: QKVBimodalCSRPool on 500 k points x min(Poisson(4), 32) views (2 M view rows), 64
+    modality channels, 16-channel keys.  The full-size forward (value encoder and element
+    encoder with their pooling epilogues) against (i) the separate launches that save_last
+    keeps, (ii) the same module run on the second half of the points alone (points are
+    independent; the 32-row tiles of the epilogues fall differently), (iii) the CPU oracle
+    on the first 3000 points."""
+    import mvf_oracle as orc
+    from mvfusion import pooling
+    rng = np.random.default_rng(3)
+    N, C = 500_000, 64
+    counts = np.minimum(rng.poisson(4, N), 32)
+    ptr_np = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    Vw = int(ptr_np[-1])
+    x_main = rng.random((N, 32), dtype=np.float32)
+    x_mod = rng.random((Vw, C), dtype=np.float32) - 0.5
+    x_map = rng.random((Vw, 8), dtype=np.float32)
+    torch.manual_seed(7)
+    mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=C, out_mod=C, num_groups=1,
+                                    nc_qk=16, gating=True)
+    gen = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+        mod.G.weight.fill_(1.2)
+        mod.G.bias.fill_(0.3)
+    sd = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+    mod = mod.to(DEV).eval()
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    xm, xo, xp, ptr = T(x_main), T(x_mod), T(x_map), T(ptr_np)
+    out = mod(xm, xo, xp, ptr)
+    assert out.shape == (N, C) and bool(torch.isfinite(out).all())
+    scale = float(out.abs().max())
+    assert scale > 1e-3
+    assert float(out[T(counts == 0)].abs().max()) == 0.0
+    mod.save_last = True
+    plain = mod(xm, xo, xp, ptr)
+    mod.save_last = False
+    torch.testing.assert_close(out, plain, rtol=1e-5, atol=1e-5 * scale)
+    h = N // 2 + 13
+    a = int(ptr_np[h])
+    half = mod(xm[h:], xo[a:], xp[a:], ptr[h:] - a)
+    torch.testing.assert_close(half, out[h:], rtol=1e-5, atol=1e-5 * scale)
+    k = 3000
+    b = int(ptr_np[k])
+    want = orc.qkv_pool(x_main[:k], x_mod[:b], x_map[:b], ptr_np[:k + 1], sd, num_groups=1, nc_qk=16,
+                        gating=True, dim_scaling=True, group_scaling=False)
+    np.testing.assert_allclose(out[:k].cpu().numpy(), want, rtol=1e-5, atol=1e-5 * scale)
