@@ -592,13 +592,15 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         }
     pool_tail:
         if (POOL) {
-            // Attention-weighted segment sum of the finished rows (pooling.py:519-530).
+            // Segment reduction of the finished rows: the attention-weighted sum
+            // (POOL 1 / 2, pooling.py:519-530) or the maximum (POOL 3, pooling.py:628).
             // The wave's 32 rows go through LDS 16 at a time: a lane writes the 32 / 64
-            // channels of its row (already times the row's attention weight), then lane c folds
-            // channel c over the staged rows in row order.  The segment of a row is
-            // wave-uniform (read from the row's lane), so segment changes are scalar
-            // branches.  A segment that lies inside the tile is stored; one that
-            // continues in a neighbouring tile is added atomically to its zeroed row.
+            // channels of its row (for the sum: times the row's attention weight), then
+            // lane c folds channel c over the staged rows in row order.  The segment of a
+            // row is wave-uniform (read from the row's lane), so segment changes are scalar
+            // branches.  A segment that lies inside the tile is stored; one that continues
+            // in a neighbouring tile is combined atomically with its preset row (zeros for
+            // the sum, -inf for the maximum).
             const bool wide = cop_of(nlayers - 1) > 32;
             const int cout = A.L[nlayers - 1].cout;
             float *stg = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
