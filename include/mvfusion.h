@@ -106,6 +106,23 @@ int mvf_camera_projection(
     int64_t *indices, float *dist, double *x_proj, double *y_proj,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
+/* mvf_camera_projection for callers that cannot allocate device memory and
+ * have no workspace to hand over (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same inputs, outputs and results as mvf_camera_projection; the
+ * per-block counts of the compaction live in a 256 KB device array inside the
+ * library (one copy per GPU, held until the process ends), so n is limited to
+ * mvf_camera_projection_noalloc_max_points() = 2^24 points; a larger n is
+ * rejected with MVF_E_INVALID.  The call allocates and frees nothing.  All
+ * calls on one GPU share that array: calls that overlap on one GPU (different
+ * streams or threads) race; serialise them. */
+int64_t mvf_camera_projection_noalloc_max_points(void);
+int mvf_camera_projection_noalloc(
+    const float *xyz, int64_t n, const mvf_view *h_view,
+    const mvf_vis_params *h_params, const uint8_t *mask,
+    int64_t *indices, float *dist, double *x_proj, double *y_proj,
+    int64_t *counters, void *stream);
+
 /* ---------------------------------------------------------------------- *
  * visibility_from_splatting  (visibility.py:1073-1195,1288-1321; pinhole
  * splats :761-827).  Z-buffer of the m splats; ties in depth go to the lower

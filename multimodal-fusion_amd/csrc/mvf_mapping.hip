@@ -11,6 +11,8 @@
 // sequential rule "strictly closer wins, first index wins a tie"
 // (visibility.py:1148-1162), independent of execution order.  The depth buffer
 // never touches HBM.
+#include <mutex>
+
 #include "mvf_common.h"
 #include "mvf_scan.h"
 
@@ -1000,6 +1002,69 @@ extern "C" int mvf_camera_projection(
     Arena ar(workspace, workspace_bytes);
     unsigned *blocks = ar.take<unsigned>(compact_workspace_elems(n));
     if (!ar.ok()) { set_error("camera_projection: workspace too small"); return MVF_E_WORKSPACE; }
+    ProjPred pred{xyz, *h_view, *h_params, mask};
+    ProjEmit emit{xyz, *h_view, *h_params, mask, (i64 *)indices, dist, x_proj, y_proj};
+    compact(pred, emit, (i64)n, blocks, (i64 *)counters, (i64)n, (i64 *)nullptr, st);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// ------------------------------------------------------------------------- //
+// camera_projection without a workspace argument and without any allocation   //
+// ------------------------------------------------------------------------- //
+// The per-block counts of the compaction live in a device array that is part
+// of the library's code object.  Every GPU holds its own copy at its own
+// address: the address is asked for once per device (with that device
+// current) and kept; host code below only ever uses that pointer, never the
+// array's name.  Calls on one GPU share the array (it is rewritten from
+// scratch by every call, nothing has to start at zero), so calls that overlap
+// on one GPU race.
+constexpr i64 NOALLOC_MAX_POINTS = 1ll << 24;                             // 16 Mi points
+constexpr size_t NOALLOC_SCRATCH_ELEMS = (size_t)(NOALLOC_MAX_POINTS / 256) + 1;   // 256 KB + 4 B
+static __device__ __align__(256) unsigned scratch[NOALLOC_SCRATCH_ELEMS];
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_scratch_mutex;
+static unsigned *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};
+
+// Device address of `scratch` on the current device (null + error set on failure).
+static unsigned *scratch_on_current_device()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        set_error("camera_projection_noalloc: no current HIP device (or index >= %d)", NOALLOC_MAX_DEVICES);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("camera_projection_noalloc: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+            return nullptr;
+        }
+        g_scratch_ptr[dev] = (unsigned *)p;
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int64_t mvf_camera_projection_noalloc_max_points(void) { return NOALLOC_MAX_POINTS; }
+
+extern "C" int mvf_camera_projection_noalloc(
+    const float *xyz, int64_t n, const mvf_view *h_view, const mvf_vis_params *h_params,
+    const uint8_t *mask, int64_t *indices, float *dist, double *x_proj, double *y_proj,
+    int64_t *counters, void *stream)
+{
+    if (int rc = check_params(h_params, "camera_projection_noalloc")) return rc;
+    MVF_REQUIRE(n >= 0 && h_view && counters, "camera_projection_noalloc: bad arguments");
+    MVF_REQUIRE(n <= NOALLOC_MAX_POINTS,
+                "camera_projection_noalloc: n=%lld exceeds the built-in scratch (at most %lld points); "
+                "use mvf_camera_projection with a workspace", (long long)n, (long long)NOALLOC_MAX_POINTS);
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { MVF_HIP(hipMemsetAsync(counters, 0, sizeof(int64_t), st)); return MVF_OK; }
+    MVF_REQUIRE(xyz && indices && dist && x_proj && y_proj, "camera_projection_noalloc: null buffer");
+    unsigned *blocks = scratch_on_current_device();
+    if (!blocks) return MVF_E_LAUNCH;
     ProjPred pred{xyz, *h_view, *h_params, mask};
     ProjEmit emit{xyz, *h_view, *h_params, mask, (i64 *)indices, dist, x_proj, y_proj};
     compact(pred, emit, (i64)n, blocks, (i64 *)counters, (i64)n, (i64 *)nullptr, st);

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "mvf_profile_read": (C.c_int, [_P, _P, C.c_int]),
     "mvf_camera_projection_workspace_bytes": (_SZ, [_I64]),
     "mvf_camera_projection": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "mvf_camera_projection_noalloc_max_points": (_I64, []),
+    "mvf_camera_projection_noalloc": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mvf_splat_visibility_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I64]),
     "mvf_splat_visibility": (C.c_int, [_P, _P, _P, _I64, _F, _F, _P, _I64, _P, _P, _P, _I64,
                                        _P, _P, _SZ, _P]),
