@@ -69,9 +69,13 @@ struct Arena {
 static inline unsigned cdiv(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
 
 // ---- projection math shared by every mapping kernel -------------------------
-// Z-buffer tiles: TILE x TILE pixels of 64-bit keys in LDS.
-constexpr int TILE = 64;
-constexpr int TILE_LOG = 6;
+// Z-buffer tiles: TILE_X x TILE_Y pixels of 64-bit keys in LDS, one workgroup of
+// TILE_X * TILE_Y / 8 threads per tile.
+#ifndef MVF_TILE_Y_LOG
+#define MVF_TILE_Y_LOG 6
+#endif
+constexpr int TILE_X_LOG = 6, TILE_Y_LOG = MVF_TILE_Y_LOG;
+constexpr int TILE_X = 1 << TILE_X_LOG, TILE_Y = 1 << TILE_Y_LOG;
 
 struct Proj {
     float dist;     // float32 distance to img_xyz

@@ -2,15 +2,17 @@
 // depth-map visibility, mapping features, and the fused all-views MapImages
 // path.  gfx950 only.
 //
-// Z-buffer design.  The image is cut into 64x64-pixel tiles.  Splats are
-// binned to the tiles they overlap (count -> scan -> fill, order inside a bin
-// is irrelevant), then one 256-thread workgroup per tile resolves its tile in
-// LDS: each pixel holds a 64-bit key  float_bits(dist) << 32 | local_index  and
-// every splat pixel does an LDS atomicMin.  dist > 0 makes the float bit
-// pattern order preserving, so the minimum key is exactly the reference's
-// sequential rule "strictly closer wins, first index wins a tie"
-// (visibility.py:1148-1162), independent of execution order.  The depth buffer
-// never touches HBM.
+// Z-buffer design.  The image is cut into tiles of TILE_X x TILE_Y pixels.
+// Splats are binned to the tiles they overlap (count -> scan -> fill, order
+// inside a bin is irrelevant), then one workgroup per tile resolves its tile in
+// LDS: a 64-bit key  float_bits(dist) << 32 | local_index  per pixel and per
+// cell of 4 vertically adjacent pixels; a splat does an LDS atomicMin on every
+// cell it covers entirely and on the pixels of its remaining rows, and the
+// depth of a pixel is the smaller of its own key and its cell's key.  dist > 0
+// makes the float bit pattern order preserving, so the minimum key is exactly
+// the reference's sequential rule "strictly closer wins, first index wins a
+// tie" (visibility.py:1148-1162), independent of execution order.  The depth
+// buffer never touches HBM.
 #include <mutex>
 
 #include "mvf_common.h"
@@ -118,15 +120,41 @@ __device__ __forceinline__ unsigned raster_lg(unsigned ch)
     return hm <= 1u ? 0u : 32u - (unsigned)__clz(hm - 1u);
 }
 
+// Raster steps of a rectangle of w x h cells (h <= 16) for a row of 16 lanes
+// shaped 2^lg >= h rows by 16 >> lg columns.
+__device__ __forceinline__ unsigned rect_steps(unsigned w, unsigned h)
+{
+    if (h == 0u) return 0u;
+    const unsigned sh = 4u - raster_lg(h);
+    return (w + (1u << sh) - 1u) >> sh;
+}
+
+// The z-buffer of a tile has two levels: pixels, and cells of ZB_CELL
+// vertically adjacent pixels (the cell grid is aligned to the image rows).  A
+// box writes its key once per cell it covers entirely and once per pixel of the
+// rows above and below its cells; the depth of a pixel is the smaller of its own
+// key and its cell's key.  Rows of the clipped box [ya, yb) that are covered by
+// whole cells: [cell_lo, cell_hi) (empty when cell_hi <= cell_lo).
+constexpr int ZB_CELL_LOG = 2;
+constexpr int ZB_CELL = 1 << ZB_CELL_LOG;
+__device__ __forceinline__ void cell_rows(int ya, int yb, int &cell_lo, int &cell_hi)
+{
+    cell_lo = (ya + ZB_CELL - 1) & ~(ZB_CELL - 1);
+    cell_hi = yb & ~(ZB_CELL - 1);
+}
+
 // Size class of a (splat, tile) pair: 0 = most expensive, classes a factor 2 apart.
 __device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
 {
-    const int x0 = tx << TILE_LOG, y0 = ty << TILE_LOG;
-    const unsigned cw = (b.xb < x0 + TILE ? b.xb : x0 + TILE) - (b.xa > x0 ? b.xa : x0);
-    const unsigned ch = (b.yb < y0 + TILE ? b.yb : y0 + TILE) - (b.ya > y0 ? b.ya : y0);
-    const unsigned sh = 4u - raster_lg(ch);                       // log2 of columns per step
-    const unsigned cost = ((ch + 15u) >> 4) * ((cw + (1u << sh) - 1u) >> sh);   // 1 .. 256
-    const int l = cost <= 1u ? 0 : 32 - __clz(cost - 1u);         // ceil(log2(cost)), 0 .. 8
+    const int x0 = tx << TILE_X_LOG, y0 = ty << TILE_Y_LOG;
+    const unsigned cw = (b.xb < x0 + TILE_X ? b.xb : x0 + TILE_X) - (b.xa > x0 ? b.xa : x0);
+    const int ya = b.ya > y0 ? b.ya : y0, yb = b.yb < y0 + TILE_Y ? b.yb : y0 + TILE_Y;
+    int lo, hi;
+    cell_rows(ya, yb, lo, hi);
+    unsigned cost;                                                 // 1 .. 64 + 2 * 16
+    if (hi > lo) cost = rect_steps(cw, (unsigned)(hi - lo) >> ZB_CELL_LOG) + rect_steps(cw, (unsigned)((lo - ya) + (yb - hi)));
+    else cost = rect_steps(cw, (unsigned)(yb - ya));
+    const int l = cost <= 1u ? 0 : 32 - __clz(cost - 1u);         // ceil(log2(cost)), 0 .. 7
     return (NCLS - 1) - (l > NCLS - 1 ? NCLS - 1 : l);
 }
 
@@ -192,8 +220,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const bool have = live && src.get(i, v, P, x, y, d, sx, sy);
     BBox b{0, 0, 0, 0};
     if (have) b = splat_bbox<Src::ANY>(x, y, d, sx, sy, P);
-    const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
-    const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
+    const int tx0 = b.xa >> TILE_X_LOG, tx1 = (b.xb - 1) >> TILE_X_LOG;
+    const int ty0 = b.ya >> TILE_Y_LOG, ty1 = (b.yb - 1) >> TILE_Y_LOG;
     const int ncnt = tiles_per_view * NCLS;
     unsigned *tc = tile_count + (size_t)v * ncnt;
     const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
@@ -247,8 +275,8 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
     e.key = 0; e.xa = e.xb = e.ya = e.yb = 0;
     if (have) e = staged[blk * 256 + tid];
     const BBox b{(int)e.xa, (int)e.xb, (int)e.ya, (int)e.yb};
-    const int tx0 = b.xa >> TILE_LOG, tx1 = (b.xb - 1) >> TILE_LOG;
-    const int ty0 = b.ya >> TILE_LOG, ty1 = (b.yb - 1) >> TILE_LOG;
+    const int tx0 = b.xa >> TILE_X_LOG, tx1 = (b.xb - 1) >> TILE_X_LOG;
+    const int ty0 = b.ya >> TILE_Y_LOG, ty1 = (b.yb - 1) >> TILE_Y_LOG;
     const int ncnt = tiles_per_view * NCLS;
     const size_t cbase = (size_t)v * ncnt;
     const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
@@ -289,65 +317,105 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(
 // ------------------------------------------------------------------------- //
 // z-buffer of one tile in LDS                                                 //
 // ------------------------------------------------------------------------- //
-// LDS image: zb[x][y], 8-byte keys, y fastest.
+// LDS image: pixel level zb[x][y], 8-byte keys, y fastest, followed by the cell
+// level zc[x][y / ZB_CELL].
 //
 // An LDS atomicMin costs the same whatever the number of active lanes
-// (measured on gfx950: about 6.3 cycles per wave-instruction per CU for 64-bit
-// keys), so the kernel is built to put as many covered pixels as possible in
-// every atomic instruction and to keep LDS waits out of the loop.  The 256
-// threads form 16 "quarters" (rows of 16 lanes).  The bin is consumed 256
-// entries at a time, 64 per wave, one entry per lane.  Each wave first orders
-// its 64 entries by decreasing pixel count (a counting sort on the size class
-// with wave ballots, one ds_permute per register), so that the four quarters
-// of the wave, which walk the ordered list four entries at a time in one
-// instruction stream, get entries of similar size.  A quarter takes its entry
-// from lane J of its row with a DPP row broadcast (no LDS traffic) and its 16
-// lanes sweep the entry's pixels 16 at a time in column-major order (pixel id
-// = x_off * h + y_off): a 5x5 splat takes 2 sweeps, a 50x50 one 157, all
-// lanes busy.
+// (measured on gfx950: about 6.5 cycles per wave-instruction per CU for 64-bit
+// keys, as much as a plain 64-bit LDS write), so the kernel is built to issue
+// as few of them as possible and to keep LDS waits out of the loop.  A box is
+// cut into two rectangles: the cells it covers entirely (cell level) and the
+// pixel rows above and below them (pixel level, swept as one rectangle with a
+// gap); a box without a whole cell is one pixel rectangle.  That cuts the
+// atomics of the mean splat by 2.6 against one atomic per pixel.  The 512 threads form 32 "quarters" (rows of
+// 16 lanes).  The bin is consumed 512 entries at a time, one entry per lane.
+// The four quarters of a wave walk the bin four entries at a time in one
+// instruction stream (the bin is ordered by raster cost, so they get entries
+// of similar size).  A quarter takes its entry from lane J of its row with DPP
+// row broadcasts (no LDS traffic) and its 16 lanes sweep each rectangle as
+// 2^lg >= h rows by 16 >> lg columns per step.
 template <int J> __device__ __forceinline__ unsigned row_bcast(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x150 + J, 0xf, 0xf, false);
 }
 
-// Column pitch of the LDS image: 64 + 9 keys.  With 32 8-byte slots per bank
+// Column pitch of the pixel level: 64 + 9 keys.  With 32 8-byte slots per bank
 // row, neighbouring columns start 9 slots apart, which keeps the 16 lanes of a
-// row on distinct slots for every lane shape (1x16, 2x8, 4x4, 8x2, 16x1).
-constexpr unsigned ZB_PITCH = TILE + 9;
+// row on distinct slots for the lane shapes 1x16, 4x4, 8x2, 16x1 (2x8: one pair
+// shares a slot).  Cell level: 16 cells per column, pitch 26.
+constexpr unsigned ZB_PITCH = TILE_Y + 9;
 constexpr unsigned ZB_PITCH_BYTES = ZB_PITCH * 8;
-static_assert(TILE * ZB_PITCH_BYTES < 65536, "byte offsets of the LDS image are staged in 16 bits");
+constexpr unsigned ZC_ROWS = TILE_Y >> ZB_CELL_LOG;
+constexpr unsigned ZC_PITCH = ZC_ROWS + (ZC_ROWS == 16 ? 10 : 2);
+constexpr unsigned ZC_PITCH_BYTES = ZC_PITCH * 8;
+constexpr unsigned ZC_BASE_BYTES = TILE_X * ZB_PITCH_BYTES;            // cell level behind the pixel level
+constexpr unsigned ZB_KEYS = TILE_X * (ZB_PITCH + ZC_PITCH);
+static_assert(ZB_KEYS * 8 < 65536, "byte offsets of the LDS image are staged in 16 bits");
+static_assert(TILE_Y * 8 + 8 <= ZB_PITCH_BYTES && ZC_ROWS * 8 + 8 <= ZC_PITCH_BYTES, "row offsets stay below the column pitch");
 
-template <int J>
-__device__ __forceinline__ void raster_entry(char *zb, const uint4 &mine, unsigned ly)
+// One rectangle of a staged entry: geom = byte offset in the LDS image of its
+// first cell | byte offset one past its last column << 16; shape = h | lg << 8 |
+// step << 16 with 2^lg = rows covered by the 16 lanes and step = byte distance
+// of 16 >> lg columns.  h = 0: no rectangle.  The pixel rows above and below the
+// cells of a box form ONE rectangle of h = top + bottom rows: its rows from
+// `top` on lie `gap` bytes further down (split = top | gap << 8).
+template <unsigned PITCH_BYTES, bool SPLIT>
+__device__ __forceinline__ void raster_rect(char *zb, u64 key, unsigned geom, unsigned shape, unsigned split, unsigned ly)
 {
-    const unsigned rx = row_bcast<J>(mine.x), ry = row_bcast<J>(mine.y);
-    const unsigned rz = row_bcast<J>(mine.z), rw = row_bcast<J>(mine.w);
-    const u64 key = ((u64)ry << 32) | rx;
-    const unsigned h = rw & 0xffu;                               // 0 for a staged miss
-    const unsigned lg = (rw >> 8) & 0xffu;
-    const unsigned step = rw >> 16;                              // bytes between column groups
-    const unsigned end = rz >> 16;                               // byte offset one past the last column
+    const unsigned h = shape & 0xffu;
+    const unsigned lg = (shape >> 8) & 0xffu;
     const unsigned xo = ly >> lg, yo = ly - (xo << lg);
-    unsigned a0 = (rz & 0xffffu) + xo * ZB_PITCH_BYTES + (yo << 3);
-    for (unsigned row = yo; row < h; row += 16u, a0 += 128u)
-        for (unsigned a = a0; a < end; a += step) atomicMin((u64 *)(zb + a), key);
+    if (yo < h) {
+        const unsigned step = shape >> 16, end = geom >> 16;
+        unsigned a = (geom & 0xffffu) + xo * PITCH_BYTES + (yo << 3);
+        if (SPLIT) a += yo >= (split & 0xffu) ? split >> 8 : 0u;
+        // (row offsets stay below the column pitch, so the last column ends before `end`)
+        for (; a < end; a += step) atomicMin((u64 *)(zb + a), key);
+    }
 }
 
-// Staged entry: key, then the byte offsets in the LDS image of the clipped
-// box's first pixel and of the column behind its last one (16 bits each), then
-// h | lg << 8 | step << 16 with 2^lg = rows covered by the 16 lanes and step =
-// byte distance of 16 >> lg columns.  h = 0 when the entry is absent or misses
-// the tile.
-__device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, bool valid)
+struct StagedEntry { unsigned klo, khi, geom[2], shape[2], split; };      // [0]: cells, [1]: pixel rows
+
+template <int J>
+__device__ __forceinline__ void raster_entry(char *zb, const StagedEntry &mine, unsigned ly)
+{
+    const u64 key = ((u64)row_bcast<J>(mine.khi) << 32) | row_bcast<J>(mine.klo);
+    raster_rect<ZC_PITCH_BYTES, false>(zb, key, row_bcast<J>(mine.geom[0]), row_bcast<J>(mine.shape[0]), 0u, ly);
+    raster_rect<ZB_PITCH_BYTES, true>(zb, key, row_bcast<J>(mine.geom[1]), row_bcast<J>(mine.shape[1]),
+                                      row_bcast<J>(mine.split), ly);
+}
+
+__device__ __forceinline__ void stage_rect(unsigned &geom, unsigned &shape, unsigned base, unsigned pitch_bytes,
+                                           unsigned xa, unsigned xb, unsigned row, unsigned h)
+{
+    const unsigned lg = raster_lg(h);
+    geom = (base + xa * pitch_bytes + (row << 3)) | ((base + xb * pitch_bytes) << 16);
+    shape = h == 0u ? 0u : h | (lg << 8) | (((16u * pitch_bytes) >> lg) << 16);
+}
+
+// The rectangles of an entry clipped to the tile at (x0, y0); all shapes are 0
+// when the entry is absent or misses the tile.
+__device__ __forceinline__ StagedEntry stage_entry(const uint4 &raw, int x0, int y0, bool valid)
 {
     int xa = (int)(raw.z & 0xffffu) - x0, xb = (int)(raw.z >> 16) - x0;
     int ya = (int)(raw.w & 0xffffu) - y0, yb = (int)(raw.w >> 16) - y0;
     xa = xa < 0 ? 0 : xa; ya = ya < 0 ? 0 : ya;
-    xb = xb > TILE ? TILE : xb; yb = yb > TILE ? TILE : yb;
-    if (!valid || xb <= xa || yb <= ya) return make_uint4(0u, 0u, 0u, 0u);
-    const unsigned h = yb - ya, lg = raster_lg(h);
-    const unsigned first = (unsigned)xa * ZB_PITCH_BYTES + ((unsigned)ya << 3), end = (unsigned)xb * ZB_PITCH_BYTES;
-    return make_uint4(raw.x, raw.y, first | (end << 16), h | (lg << 8) | (((16u * ZB_PITCH_BYTES) >> lg) << 16));
+    xb = xb > TILE_X ? TILE_X : xb; yb = yb > TILE_Y ? TILE_Y : yb;
+    StagedEntry e;
+    e.klo = raw.x; e.khi = raw.y;
+    if (!valid || xb <= xa || yb <= ya) { xb = xa = 0; yb = ya = 0; }
+    int lo, hi;
+    cell_rows(ya, yb, lo, hi);
+    if (hi > lo) {
+        stage_rect(e.geom[0], e.shape[0], ZC_BASE_BYTES, ZC_PITCH_BYTES, xa, xb, lo >> ZB_CELL_LOG, (hi - lo) >> ZB_CELL_LOG);
+        stage_rect(e.geom[1], e.shape[1], 0u, ZB_PITCH_BYTES, xa, xb, ya, (lo - ya) + (yb - hi));
+        e.split = (unsigned)(lo - ya) | ((unsigned)(hi - lo) << (3 + 8));
+    } else {
+        e.geom[0] = e.shape[0] = 0u;
+        stage_rect(e.geom[1], e.shape[1], 0u, ZB_PITCH_BYTES, xa, xb, ya, yb - ya);
+        e.split = 0xffu;                       // no row reaches the split
+    }
+    return e;
 }
 
 // Scan of the [tile][class] counters, one tile per thread: exclusive offsets,
@@ -363,7 +431,10 @@ __device__ __forceinline__ uint4 stage_entry(const uint4 &raw, int x0, int y0, b
 // and the cheap ones even out the finish times.
 struct TileDesc { unsigned begin, end, view, origin; };   // origin = x0 | y0 << 16
 constexpr int ZB_BUCKETS = 64;
-constexpr unsigned ZB_TILE_FIXED_COST = 256;    // readout + reset of a tile, in raster steps
+#ifndef MVF_ZB_TILE_FIXED_COST
+#define MVF_ZB_TILE_FIXED_COST 256
+#endif
+constexpr unsigned ZB_TILE_FIXED_COST = MVF_ZB_TILE_FIXED_COST;    // readout + reset of a tile, in raster steps
 
 // Entries of a tile (low 32 bits) and its cost bucket + 1 (0 = empty tile) above.
 __device__ __forceinline__ u64 tile_weight(const uint4 &a, const uint4 &b)
@@ -434,7 +505,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
             const unsigned slot = h_base[bk] + h_front[bk] + atomicAdd(&h_blk[bk], 1u);
             const unsigned v = (unsigned)t / (unsigned)tiles_per_view, lt = (unsigned)t - v * tiles_per_view;
             const unsigned tx = lt / (unsigned)tiles_y, ty = lt - tx * tiles_y;
-            descs[slot] = TileDesc{begin, run, v, (tx << TILE_LOG) | (ty << (TILE_LOG + 16))};
+            descs[slot] = TileDesc{begin, run, v, (tx << TILE_X_LOG) | (ty << (TILE_Y_LOG + 16))};
         }
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
@@ -451,7 +522,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
 // WRITE_IDMAP: store winner + 1 of every pixel of a non-empty tile to
 // idmap[v][x][y] (the caller pre-zeroes idmap).  Otherwise mark
 // seen[winner][v] = 1 (exact mode; seen_stride bytes per point).
-constexpr int ZB_THREADS = 512;                 // 8 waves per tile: 4 workgroups = 32 waves per CU
+constexpr int ZB_THREADS = TILE_X * TILE_Y / 8;  // one 8-pixel column piece per thread
+#ifndef MVF_ZB_WG_PER_CU
+#define MVF_ZB_WG_PER_CU (MVF_TILE_Y_LOG == 6 ? 3 : 6)
+#endif
+constexpr int ZB_WG_PER_CU = MVF_ZB_WG_PER_CU;  // 50 KB of LDS each
 constexpr int ZB_QUARTERS = ZB_THREADS / 16;
 
 #ifdef MVF_ZB_DEBUG
@@ -482,7 +557,7 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     int tiles_y, int tiles_per_view, int W, int Hc, uint8_t *__restrict__ seen, i64 seen_stride,
     unsigned *__restrict__ idmap)
 {
-    __shared__ u64 zb[TILE * ZB_PITCH];
+    __shared__ __align__(16) u64 zb[ZB_KEYS];
     __shared__ unsigned s_next;
     const unsigned nd = *n_desc;
     if (blockIdx.x >= nd) return;
@@ -525,7 +600,7 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     if (begin > end) begin = end;
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
     if (begin + slot < end) raw = *(const uint4 *)(entries + begin + slot);
-    for (int p = tid; p < (int)(TILE * ZB_PITCH); p += ZB_THREADS) zb[p] = ZB_EMPTY;
+    for (int p = tid; p < (int)ZB_KEYS; p += ZB_THREADS) zb[p] = ZB_EMPTY;
     __syncthreads();
     ZBT(0);
 
@@ -545,7 +620,7 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
         do {
             const i64 rem = end - base;
             ZBT(1);
-            const uint4 mine = stage_entry(raw, x0, y0, slot < rem);
+            const StagedEntry mine = stage_entry(raw, x0, y0, slot < rem);
             ZBT(2);
             uint4 nxt = make_uint4(0u, 0u, 0u, 0u);
             if (base + ZB_THREADS < end) {
@@ -556,6 +631,10 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
                 // entries, a ticket, a descriptor); nothing of it is looked
                 // at before the raster loop below is through
                 if (more && nbegin + slot < nend) raw_n = *(const uint4 *)(entries + nbegin + slot);
+#ifdef MVF_ZB_DEBUG
+                if (ZBD(8)) ticket = 0;            // static round-robin instead of tickets (timing only)
+                else
+#endif
                 if (more && tid == 0) ticket = atomicAdd(queue, 1u);
                 if (k2 < nd) d2 = descs[k2];
             }
@@ -578,44 +657,51 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
         ZBT(5);
 
         // read out the tile and reset it for the next one: every thread owns 8
-        // vertically adjacent pixels (one 64-byte piece of a column)
+        // vertically adjacent pixels (one 64-byte piece of a column) and the two
+        // cells above them.  A row of 16 lanes holds the same rows of 16
+        // neighbouring columns, so the winner to the left of a pixel is a DPP
+        // shift away.
         if (!ZBD(4)) {
-            static_assert((TILE * TILE / 8) % ZB_THREADS == 0, "whole 8-pixel pieces per thread");
+            static_assert(ZB_CELL == 4, "two cells per piece");
+            constexpr int RBS = TILE_Y / 8;                              // pieces per column
+            const int rb = (tid >> 4) & (RBS - 1);                       // rows 8 rb .. 8 rb + 7
+            const int col = ((tid >> 4) / RBS) * 16 + (tid & 15);
+            u64 *px = zb + col * ZB_PITCH + rb * 8;
+            u64 *cl = zb + TILE_X * ZB_PITCH + col * ZC_PITCH + rb * 2;
+            u64 key[8];
 #pragma unroll
-            for (int piece = tid; piece < TILE * TILE / 8; piece += ZB_THREADS) {
-                u64 *cell = zb + (piece >> 3) * ZB_PITCH + (piece & 7) * 8;
-                unsigned id[8], left[8];
+            for (int k = 0; k < 8; ++k) key[k] = px[k];
+            const u64 c0 = cl[0], c1 = cl[1];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) id[k] = (unsigned)cell[k];      // empty cells read 0xffffffff
-                // Winner of the same row in the column to the left.  That column
-                // belongs to lane - 8 of the same wave in the same step, whose
-                // reset below comes after this read in program order; the first
-                // 8 lanes of a wave would race with another wave and go without.
-                const bool has_left = (tid & 63) >= 8;
+            for (int k = 0; k < 8; ++k) px[k] = ZB_EMPTY;
+            cl[0] = ZB_EMPTY; cl[1] = ZB_EMPTY;
+            unsigned id[8];                                   // empty pixels give 0xffffffff
 #pragma unroll
-                for (int k = 0; k < 8; ++k) left[k] = has_left ? (unsigned)cell[k - (int)ZB_PITCH] : 0xffffffffu;
+            for (int k = 0; k < 8; ++k) {
+                const u64 c = k < 4 ? c0 : c1;
+                id[k] = (unsigned)(key[k] < c ? key[k] : c);
+            }
+            if (WRITE_IDMAP) {
+                const int gx = x0 + col, gy = y0 + rb * 8;
+                if (gx < W) {
+                    unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) cell[k] = ZB_EMPTY;
-                if (WRITE_IDMAP) {
-                    const int gx = x0 + (piece >> 3), gy = y0 + (piece & 7) * 8;
-                    if (gx < W) {
-                        unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
+                    for (int k = 0; k < 8; ++k)
+                        if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
+                }
+            } else {
+                // A winner is marked where neither the pixel above (inside the
+                // piece) nor the pixel to the left (the first lane of a row goes
+                // without) shows it: its top-left visible pixel always qualifies.
+                uint8_t *sv = seen + v;
+                unsigned prev = 0xffffffffu;
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
-                    }
-                } else {
-                    uint8_t *sv = seen + v;
-                    // a winner is marked where neither the pixel above (inside the
-                    // piece) nor the pixel to the left shows it: its top-left
-                    // visible pixel always qualifies
-                    unsigned prev = 0xffffffffu;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (id[k] != prev && id[k] != left[k] && id[k] != 0xffffffffu && !ZBD(2))
-                            sv[(size_t)id[k] * seen_stride] = 1;
-                        prev = id[k];
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    // row_shr:1, lanes without a source keep "empty"
+                    const unsigned left = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)id[k], 0x111, 0xf, 0xf, false);
+                    if (id[k] != prev && id[k] != left && id[k] != 0xffffffffu && !ZBD(2))
+                        sv[(size_t)id[k] * seen_stride] = 1;
+                    prev = id[k];
                 }
             }
         }
@@ -628,6 +714,9 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
           if (tid == 0 && kc_ < 16384) { g_zb_tile[kc_ * 2] = (unsigned)last_dur_; g_zb_tile[kc_ * 2 + 1] = (unsigned)last_n_; } }
 #endif
         if (!more) break;
+#ifdef MVF_ZB_DEBUG
+        if (ZBD(8)) { if (tid == 0) s_next = k2 + gridDim.x; } else
+#endif
         if (tid == 0) s_next = 3u * gridDim.x + q + ticket * ZB_QUEUES;
 #ifdef MVF_ZB_SPAN
         kc_ = k1;
@@ -1072,18 +1161,20 @@ extern "C" int mvf_camera_projection_noalloc(
     return MVF_OK;
 }
 
-// Persistent z-buffer grid: 4 workgroups of 512 threads (32 KB LDS each) per CU.
+// Persistent z-buffer grid: 3 workgroups of 512 threads (50 KB LDS each) per CU.
 static unsigned zb_grid(i64 tiles)
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    // compute units of each device, asked for once per device
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+        int c = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        cus[dev] = c > 0 ? c : 256;
     }
-    const i64 g = (i64)cus * 4;
+    const i64 g = (i64)cus[dev] * ZB_WG_PER_CU;
     return (unsigned)(tiles < g ? tiles : g);
 }
 
@@ -1101,14 +1192,14 @@ static inline i64 seen_row_bytes(int V) { return ((i64)V + 15) / 16 * 16; }
 static inline void tile_grid(const mvf_vis_params &P, int &tiles_x, int &tiles_y, int &Hc)
 {
     Hc = P.H - P.crop_top - P.crop_bottom;
-    tiles_x = (P.W + TILE - 1) / TILE;
-    tiles_y = (Hc + TILE - 1) / TILE;
+    tiles_x = (P.W + TILE_X - 1) / TILE_X;
+    tiles_y = (Hc + TILE_Y - 1) / TILE_Y;
 }
 
 extern "C" size_t mvf_splat_visibility_workspace_bytes(
     int64_t m, int32_t W, int32_t H, int64_t pair_capacity)
 {
-    const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t tiles = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     const size_t npix = (size_t)W * H;
     size_t b = 0;
     b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;         // count, off, cur
@@ -1273,7 +1364,7 @@ extern "C" int mvf_mapping_features(
 extern "C" size_t mvf_map_images_workspace_bytes(
     int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
 {
-    const size_t tiles = (size_t)V * ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    const size_t tiles = (size_t)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
     const size_t words = (size_t)(V + 31) / 32;
     size_t b = 0;

@@ -11,7 +11,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libmvfusion.so")
+# MVFUSION_SO: an instrumented build of the same library (profiling scripts only)
+SO_PATH = os.environ.get("MVFUSION_SO") or os.path.join(_HERE, "libmvfusion.so")
 
 CAMERAS = {"kitti360_perspective": 0, "scannet": 1, "kitti360_fisheye": 2,
            "s3dis_equirectangular": 3}
