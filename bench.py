@@ -321,7 +321,7 @@ def main():
         return x_max, x_mean, P
 
     # Consecutive samples are independent: steps alternate between two streams
-    # (each with its own plan: outputs, workspace, centre map), so that the
+    # (each with its own plan: outputs and workspace), so that the
     # latency-bound kernels of one step overlap with the other step's.  On each
     # stream the mapping pass of the next step is enqueued before the sizes of
     # the current one are waited for, so the device does not idle on the host
@@ -329,7 +329,7 @@ def main():
     n_lanes = max(1, args.lanes)
     plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
     streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
-    # set-up: every lane allocates its outputs, workspace and centre map once
+    # set-up: every lane allocates its outputs and workspace once
     for p_, s_ in zip(plans, streams):
         with torch.cuda.stream(s_):
             p_.run()

@@ -203,21 +203,24 @@ int mvf_mapping_features(
  * features ([Vw][F]) with room for out_capacity views; view_seen [V] flags.
  * Since every (point, view) maps to one pixel the nested pixel pointers are
  * arange(Vw+1) and are not written.
- * counters[0] <- Vw, [1] <- (splat, tile) pairs needed, [2] <- overflow flag,
+ * counters[0] <- Vw, [1] <- (splat, tile) pairs needed, [2] <- overflow flags
+ * (bit 0: pair_capacity or out_capacity exceeded, bit 1: centre table full;
+ * outputs are then incomplete: call again with larger sizes),
  * [3] <- number of views with at least one mapping.
- * `centre_ws`: persistent scratch of V*W*Hc uint64, zero-filled ONCE by the
- * caller and then only passed back with a strictly increasing `epoch` >= 1.
+ * centre_slots: size of the hash table (inside the workspace) that resolves
+ * seen points sharing a centre pixel; rounded up to a power of two; about 2.5
+ * times the expected number of mappings keeps probing short.
  * ---------------------------------------------------------------------- */
 size_t mvf_map_images_workspace_bytes(
     int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points,
-    int64_t pair_capacity);
+    int64_t pair_capacity, int64_t centre_slots);
 int mvf_map_images_exact(
     const float *xyz, const int64_t *point_ids, const int64_t *inv_ids,
     int64_t n, int64_t num_points, const mvf_view *views, int32_t V,
     const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
     const float *linearity, const float *planarity, const float *scattering,
     const float *normals, int32_t proj_upscale, int32_t downscale,
-    int32_t crop_w, int32_t crop_h, uint64_t *centre_ws, uint32_t epoch,
+    int32_t crop_w, int32_t crop_h, int64_t centre_slots,
     int64_t pair_capacity, int64_t *pointers, int64_t *images, int16_t *pixels,
     float *features, int64_t out_capacity, int32_t *view_seen,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);

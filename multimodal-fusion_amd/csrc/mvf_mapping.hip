@@ -860,10 +860,49 @@ __global__ __launch_bounds__(256) void features_kernel(
 // ------------------------------------------------------------------------- //
 // After the tile pass seen[i][v] (one byte per view, rows of seen_stride bytes,
 // a multiple of 16) tells which points own a z-buffer pixel.
-// centre_ws[v][x][y] is a persistent 64-bit map: atomicMax of
-// (epoch << 32 | i + 1) keeps, per centre pixel, the highest local index of
-// this call -- the reference's ascending overwrite (visibility.py:1183-1187);
-// entries of earlier calls carry a smaller epoch and always lose.
+// Seen points that share a centre pixel of a view: the one with the highest
+// local index keeps the pixel -- the reference's ascending overwrite
+// (visibility.py:1183-1187).  The seen (view, pixel) pairs are few against the
+// V * W * Hc pixels, so they go into an open-addressing hash table (linear
+// probing, sized by the caller to a few times the number of mappings, cleared
+// by the count pass).  A slot is one 64-bit word, pixel id + 1 above index + 1:
+// a point claims an empty slot with one compare-and-swap; only points that
+// really share a pixel need a second atomic (a maximum, which keeps the pixel
+// id and raises the index).
+struct CentreTable { u64 *slots; unsigned mask; int shift; };       // mask + 1 = 2^(64 - shift) slots
+constexpr int CENTRE_MAX_PROBES = 512;
+
+__device__ __forceinline__ unsigned centre_pixel_id(int v, int cx, int cy, int W, int Hc)
+{
+    return ((unsigned)v * (unsigned)W + (unsigned)cx) * (unsigned)Hc + (unsigned)cy + 1u;   // host checks V W Hc < 2^32 - 1
+}
+__device__ __forceinline__ unsigned centre_hash(const CentreTable &T, unsigned id)
+{
+    return (unsigned)(((u64)id * 0x9E3779B97F4A7C15ull) >> T.shift);
+}
+// Registers index i at pixel `id`; false when the table is too full.
+__device__ __forceinline__ bool centre_insert(const CentreTable &T, unsigned id, unsigned i)
+{
+    const u64 mine = ((u64)id << 32) | (u64)(i + 1u);
+    unsigned s = centre_hash(T, id);
+    for (int probe = 0; probe < CENTRE_MAX_PROBES; ++probe, s = (s + 1u) & T.mask) {
+        const u64 old = atomicCAS(&T.slots[s], 0ull, mine);
+        if (old == 0ull) return true;
+        if ((unsigned)(old >> 32) == id) { atomicMax(&T.slots[s], mine); return true; }
+    }
+    return false;
+}
+// Highest index + 1 registered at pixel `id` (0 = none).
+__device__ __forceinline__ unsigned centre_lookup(const CentreTable &T, unsigned id)
+{
+    unsigned s = centre_hash(T, id);
+    for (int probe = 0; probe < CENTRE_MAX_PROBES; ++probe, s = (s + 1u) & T.mask) {
+        const u64 k = T.slots[s];
+        if ((unsigned)(k >> 32) == id) return (unsigned)k;
+        if (k == 0ull) return 0u;
+    }
+    return 0u;
+}
 
 // Bit mask of the views [16 * chunk, 16 * chunk + 16) that see point i.
 __device__ __forceinline__ unsigned seen_chunk(const uint8_t *seen, i64 seen_stride, i64 i, int chunk)
@@ -895,7 +934,7 @@ __device__ __forceinline__ CloudSrc views_to_lds(CloudSrc src, int V, mvf_view *
 
 __global__ __launch_bounds__(256) void mi_centre_kernel(
     CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int V, int Hc,
-    u64 *__restrict__ centre_ws, unsigned epoch)
+    CentreTable table, i64 *__restrict__ overflow)
 {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     src = views_to_lds(src, V, (mvf_view *)dyn_lds);
@@ -909,7 +948,8 @@ __global__ __launch_bounds__(256) void mi_centre_kernel(
             double x, y, fx, fy; float d;
             if (!src.get(i, v, P, x, y, d, fx, fy)) continue;
             const int cx = (int)x, cy = (int)y - P.crop_top;
-            atomicMax(&centre_ws[((size_t)v * P.W + cx) * Hc + cy], ((u64)epoch << 32) | (u64)((unsigned)i + 1u));
+            if (!centre_insert(table, centre_pixel_id(v, cx, cy, P.W, Hc), (unsigned)i))
+                atomicOr((unsigned long long *)overflow, 2ull);
         }
     }
 }
@@ -922,14 +962,13 @@ struct PixelXform { int up, down, crop_w, crop_h; };
 // as seen, image.py:289-290,350), 2 = kept.
 __device__ __forceinline__ int mi_survives(
     const CloudSrc &src, const mvf_vis_params &P, int Hc,
-    const u64 *centre_ws, unsigned epoch, const PixelXform &X, i64 i, int v,
+    const CentreTable &table, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
     double x, y, fx, fy;
     if (!src.get(i, v, P, x, y, dist, fx, fy)) return 0;
     const int cx = (int)x, cy = (int)y;
-    const u64 want = ((u64)epoch << 32) | (u64)((unsigned)i + 1u);
-    if (centre_ws[((size_t)v * P.W + cx) * Hc + (cy - P.crop_top)] != want) return 0;
+    if (centre_lookup(table, centre_pixel_id(v, cx, cy - P.crop_top, P.W, Hc)) != (unsigned)i + 1u) return 0;
     // image.py:307-319 (non-negative operands: floor division == truncation)
     px = cx / X.up - src.views[v].crop_off_x;
     py = cy / X.up - src.views[v].crop_off_y;
@@ -958,7 +997,7 @@ __device__ __forceinline__ void mi_pixel(
 // mapping count.
 __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int Hc,
-    const u64 *__restrict__ centre_ws, unsigned epoch, PixelXform X, int V,
+    CentreTable table, PixelXform X, int V,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
@@ -980,7 +1019,7 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
             sm &= sm - 1;
             const int v = (wd << 5) + bit;
             int px, py; float d; double yp;
-            const int s = mi_survives(src, P, Hc, centre_ws, epoch, X, i, v, px, py, d, yp);
+            const int s = mi_survives(src, P, Hc, table, X, i, v, px, py, d, yp);
             if (s) view_seen[v] = 1;
             if (s == 2) kept |= 1u << bit;
         }
@@ -1046,7 +1085,7 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
                 write_features(features + (size_t)k * A.F, A, i, px3, py3, pz3,
                                src.views[v].img_xyz, d, yp);
             } else {
-                counters[2] = 1;
+                atomicOr((unsigned long long *)&counters[2], 1ull);
             }
             ++k;
         }
@@ -1361,8 +1400,18 @@ extern "C" int mvf_mapping_features(
     return MVF_OK;
 }
 
+// Number of slots of the centre-pixel table for a requested size: a power of
+// two, at least 1024.
+static inline i64 centre_table_slots(i64 requested)
+{
+    i64 t = 1024;
+    while (t < requested && t < (1ll << 31)) t <<= 1;
+    return t;
+}
+
 extern "C" size_t mvf_map_images_workspace_bytes(
-    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity,
+    int64_t centre_slots)
 {
     const size_t tiles = (size_t)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
@@ -1375,6 +1424,7 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     b += align_up((size_t)seen_row_bytes(V) * (size_t)(n > 0 ? n : 1));         // seen
     b += align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned));  // masks
     b += align_up(nb * sizeof(unsigned));                                        // block sums
+    b += align_up((size_t)centre_table_slots(centre_slots) * sizeof(u64));
     return b;
 }
 
@@ -1383,7 +1433,7 @@ extern "C" int mvf_map_images_exact(
     int64_t num_points, const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
     int32_t cylinder, const uint8_t *mask, const float *linearity, const float *planarity,
     const float *scattering, const float *normals, int32_t proj_upscale, int32_t downscale,
-    int32_t crop_w, int32_t crop_h, uint64_t *centre_ws, uint32_t epoch, int64_t pair_capacity,
+    int32_t crop_w, int32_t crop_h, int64_t centre_slots, int64_t pair_capacity,
     int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
     int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
 {
@@ -1391,11 +1441,14 @@ extern "C" int mvf_map_images_exact(
     if (int rc = check_params(h_params, "map_images_exact")) return rc;
     MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= 65535,
                 "map_images_exact: bad sizes n=%lld V=%d", (long long)n, V);
-    MVF_REQUIRE(xyz && inv_ids && views && centre_ws && pointers && images && pixels && features &&
+    MVF_REQUIRE(xyz && inv_ids && views && pointers && images && pixels && features &&
                 view_seen && counters, "map_images_exact: null buffer");
-    MVF_REQUIRE(epoch >= 1 && proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 &&
-                pair_capacity >= 1 && out_capacity >= 0, "map_images_exact: bad scalar argument");
+    MVF_REQUIRE(proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 &&
+                pair_capacity >= 1 && out_capacity >= 0 && centre_slots >= 1,
+                "map_images_exact: bad scalar argument");
     MVF_REQUIRE(h_params->exact, "map_images_exact: params.exact must be set");
+    MVF_REQUIRE((double)V * h_params->W * h_params->H < 4294967295.0,
+                "map_images_exact: V * W * H = %d * %d * %d does not fit 32 bits", V, h_params->W, h_params->H);
     MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
                 "map_images_exact: pinhole cameras only");
     const mvf_vis_params P = *h_params;
@@ -1406,12 +1459,18 @@ extern "C" int mvf_map_images_exact(
     const i64 tiles = (i64)tiles_per_view * V;
     const i64 nb = cdiv(num_points, 256);
     const int words = (V + 31) / 32;
+    const i64 slots = centre_table_slots(centre_slots);
+    int slots_log = 0;
+    while ((1ll << slots_log) < slots) ++slots_log;
 
     Arena ar(workspace, workspace_bytes);
     // counters are [tile][class]; two extra words behind tile_count: number of
     // non-empty tiles, z-buffer ticket counter
     const i64 ncnt = tiles * NCLS;
     unsigned *tile_count = ar.take<unsigned>(ncnt + BIN_TAIL);
+    // the centre table sits right behind the counters: one memset clears both
+    CentreTable table{ar.take<u64>((size_t)slots), (unsigned)(slots - 1), 64 - slots_log};
+    const size_t clear_bytes = ar.off;
     unsigned *tile_cur = ar.take<unsigned>(ncnt + BIN_TAIL);
     unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
     TileDesc *descs = ar.take<TileDesc>(tiles + 1);
@@ -1425,7 +1484,7 @@ extern "C" int mvf_map_images_exact(
     if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
-    MVF_HIP(hipMemsetAsync(tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
+    MVF_HIP(hipMemsetAsync(tile_count, 0, clear_bytes, st));
     prof_mark("memset", st);
 
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
@@ -1445,13 +1504,13 @@ extern "C" int mvf_map_images_exact(
                        seen, seen_stride, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, V, Hc,
-                       (u64 *)centre_ws, epoch);
+                       table, (i64 *)counters + 2);
     prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
     hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, Hc,
-                       (const u64 *)centre_ws, epoch, X, V, (const i64 *)inv_ids, (i64)num_points,
+                       table, X, V, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
     prof_mark("point_mask", st);
     hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,

@@ -97,25 +97,6 @@ def pack_views(images, camera):
     return torch.from_numpy(buf)
 
 
-class _CentreWorkspace:
-    """Persistent per-device uint64 map shared by successive fused calls: it is
-    zeroed once, every call tags its entries with a fresh epoch.  Calls that
-    may run concurrently (plans driven on different streams) must not share a
-    map -- a later epoch would overwrite the stamps of a pass still in flight --
-    so every ``lane`` has its own."""
-    _cache = {}
-
-    @classmethod
-    def get(cls, device, n_elems, lane=0):
-        key = (device.index, lane)
-        ws = cls._cache.get(key)
-        if ws is None or ws[0].numel() < n_elems or ws[1] >= 2 ** 32 - 2:
-            ws = [torch.zeros(n_elems, dtype=torch.int64, device=device), 0]
-            cls._cache[key] = ws
-        ws[1] += 1
-        return ws[0], ws[1]
-
-
 class FusedMapPlan:
     """One sample staged on the device for ``mvf_map_images_exact`` plus the
     output / workspace buffers, which are reused from run to run and grown when
@@ -132,7 +113,7 @@ class FusedMapPlan:
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
-                 lane=0):
+                 lane=0, centre_slots=None):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
         self.views, self.mask, self.params = views, mask, params
         self.cylinder, self.upscale, self.downscale, self.crop_size = \
@@ -141,6 +122,9 @@ class FusedMapPlan:
         self.F = 2 + sum(a is not None for a in attrs)
         self.pair_cap = pair_cap or (self.N * V // 4 + 4096)
         self.out_cap = out_cap or (self.N * V // 4 + 4096)
+        # slots of the table that resolves shared centre pixels (the library
+        # rounds up to a power of two); fitted to the mappings after a run
+        self.centre_slots = centre_slots or max(self.N * V // 8, 65536)
         self._slots = [None] * self.SLOTS
         self._ws = None
         self._turn = 0
@@ -149,11 +133,12 @@ class FusedMapPlan:
 
     def twin(self, lane):
         """A second plan over the same staged sample with its own outputs,
-        workspace and centre map, to be driven on another stream."""
+        and workspace, to be driven on another stream."""
         return FusedMapPlan(
             self.pos, self.ids, self.inv, self.attrs, self.views, self.mask, self.params,
             self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
-            self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane)
+            self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane,
+            centre_slots=self.centre_slots)
 
     def _slot(self, k):
         """Output buffers of slot k: (out_cap, counters, host counters, event,
@@ -175,11 +160,13 @@ class FusedMapPlan:
         return sl
 
     def _workspace(self):
-        if self._ws is None or self._ws[0] != self.pair_cap:
+        key = (self.pair_cap, self.centre_slots)
+        if self._ws is None or self._ws[0] != key:
             lib = L.load()
             ws_bytes = lib.mvf_map_images_workspace_bytes(
-                self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
-            self._ws = (self.pair_cap, L.workspace(ws_bytes, self.device))
+                self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
+                self.centre_slots)
+            self._ws = (key, L.workspace(ws_bytes, self.device))
         return self._ws[1]
 
     def launch(self, slot=0):
@@ -187,8 +174,6 @@ class FusedMapPlan:
         synchronisation).  Returns the slot's buffers."""
         lib = L.load()
         P = self.params
-        Hc = P.H - P.crop_top - P.crop_bottom
-        centre_ws, epoch = _CentreWorkspace.get(self.device, self.V * P.W * Hc, self.lane)
         sl = self._slot(slot)
         _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = sl
         ws = self._workspace()
@@ -197,7 +182,7 @@ class FusedMapPlan:
                 L.ptr(self.pos), L.ptr(self.ids), L.ptr(self.inv), self.N, self.num_points,
                 L.ptr(self.views), self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
                 *[L.ptr(a) for a in self.attrs], self.upscale, self.downscale,
-                int(self.crop_size[0]), int(self.crop_size[1]), L.ptr(centre_ws), epoch,
+                int(self.crop_size[0]), int(self.crop_size[1]), self.centre_slots,
                 self.pair_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(pixels),
                 L.ptr(feats), self.out_cap, L.ptr(view_seen), L.ptr(counters),
                 L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
@@ -215,21 +200,36 @@ class FusedMapPlan:
             sl[3].record(torch.cuda.current_stream(self.device))
         return PendingMap(self, sl)
 
-    def _grow(self, n_map, pairs):
-        self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
-        self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
+    def _fit(self, n_map):
+        """Sizes the centre-pixel table to the mappings seen (about 2.5 slots
+        per mapping before the library rounds up to a power of two)."""
+        def pow2(x):
+            return 1 << max(int(x) - 1, 1).bit_length()
+        target = max(int(2.5 * n_map), 4096)
+        if pow2(target) != pow2(self.centre_slots):
+            self.centre_slots = target
+
+    def _grow(self, n_map, pairs, overflow=1):
+        """Larger buffers after an overflow (bit 0: pairs / outputs, bit 1: the
+        centre-pixel table)."""
+        if overflow & 1:
+            self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
+            self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
+        if overflow & 2:
+            self.centre_slots = max(4 * self.centre_slots, 4 * n_map)
 
     def run(self):
         """Mapping pass + read-back of the data-dependent sizes (one
         synchronisation); repeats with larger buffers after an overflow.
         Returns pointers, images, pixels, features, view_seen."""
-        for _ in range(3):
+        for _ in range(4):
             _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = self.launch(0)
             n_map, pairs, overflow, n_seen = counters.tolist()
             self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
             if not overflow:
+                self._fit(n_map)
                 return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
-            self._grow(n_map, pairs)
+            self._grow(n_map, pairs, overflow)
         raise L.MvfError("MapImages: buffers still too small after retries")
 
 
@@ -247,9 +247,10 @@ class PendingMap:
         event.synchronize()
         n_map, pairs, overflow, n_seen = host.tolist()
         if overflow:
-            self.plan._grow(n_map, pairs)
+            self.plan._grow(n_map, pairs, overflow)
             return self.plan.run()
         self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
+        self.plan._fit(n_map)
         return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
 
 
@@ -278,6 +279,7 @@ class MapImages(ImageTransform):
         self.kwargs = kwargs
         self._pair_cap = None
         self._out_cap = None
+        self._centre_slots = None
         self.timings = {}
 
     # ------------------------------------------------------------------ #
@@ -295,7 +297,8 @@ class MapImages(ImageTransform):
         return (self.method == 'SplattingVisibility' and bool(visi_model.exact)
                 and visi_model.camera in ('kitti360_perspective', 'scannet')
                 and ints and images.pixel_dtype == torch.int16
-                and images.is_pinhole and images.has_extrinsic)
+                and images.is_pinhole and images.has_extrinsic
+                and images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1)
 
     def _settle(self, data, images):
         """Checks and image settings of image.py:192-215; returns the
@@ -341,7 +344,7 @@ class MapImages(ImageTransform):
         streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
         pending = []
         for k, (_, _, _, plan) in enumerate(staged):
-            plan.lane = k % n_lanes          # one centre map per stream
+            plan.lane = k % n_lanes
             s = streams[plan.lane]
             plan._slot(0)                    # buffers belong to the caller's stream
             plan._workspace()
@@ -357,6 +360,7 @@ class MapImages(ImageTransform):
             results.append(res)
             self._pair_cap = max(self._pair_cap or 0, plan.pair_cap)
             self._out_cap = max(self._out_cap or 0, plan.out_cap)
+            self._centre_slots = max(self._centre_slots or 0, plan.centre_slots)
         for s in streams:
             current.wait_stream(s)
         data_out, images_out = [], []
@@ -422,7 +426,8 @@ class MapImages(ImageTransform):
             if images.mask is not None else None,
             visibility_module.make_params(**visi_model.__dict__), bool(self.cylinder),
             int(images.proj_upscale), int(images.downscale), tuple(images.crop_size),
-            images.num_views, num_points, device, self._pair_cap, self._out_cap)
+            images.num_views, num_points, device, self._pair_cap, self._out_cap,
+            centre_slots=self._centre_slots)
 
     def _process_fused(self, data, images, visi_model, device):
         plan = self.prepare_fused(data, images, visi_model, device)
@@ -430,6 +435,7 @@ class MapImages(ImageTransform):
             return None
         pointers, img_ids, pixels, feats, view_seen = plan.run()
         self._pair_cap, self._out_cap = plan.pair_cap, plan.out_cap
+        self._centre_slots = plan.centre_slots
         if img_ids.shape[0] == 0:
             raise ValueError(_NO_MAPPING_MSG)
         mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)

@@ -264,14 +264,20 @@ def test_fused_plan_async_matches_sync():
     for g_, w_ in zip(rd, want):
         assert torch.equal(g_, w_)
     assert plan.out_cap > 16 and plan.pair_cap > 16
+    # a centre-pixel table far too small for the seen pairs: reported, grown, repeated
+    plan.centre_slots = 1
+    re_ = [x.clone() for x in plan.run()]
+    for g_, w_ in zip(re_, want):
+        assert torch.equal(g_, w_)
+    assert plan.centre_slots >= want[1].shape[0]
 
 
 def test_fused_plans_on_concurrent_streams():
     """Three plans over two different samples driven on three streams at once
     (what bench.py does with consecutive steps): every pass returns exactly
     what a lone synchronous pass returns.  The plans own separate workspaces
-    and centre maps (lanes); sharing a centre map between passes in flight
-    would let the later epoch erase the earlier pass's stamps."""
+    (tile bins, seen flags, centre-pixel table), so passes in flight share
+    nothing but their inputs."""
     from mvfusion import visibility as visibility_module
     from mvfusion.transforms import MapImages
     dev0 = torch.device("cuda", 0)
