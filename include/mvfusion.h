@@ -226,6 +226,29 @@ int mvf_map_images_exact(
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * MapImages._process with DepthBasedVisibility, all V views of one sample in
+ * one launch set (core/data_transform/multimodal/image.py:192-428;
+ * visibility_from_depth_map, core/multimodal/visibility.py:1361-1388; then
+ * ImageMapping.from_dense, core/multimodal/image.py:1738-1805).
+ * Arguments as for mvf_map_images_exact (the order of xyz does not matter here:
+ * the depth test has no ties); depth_maps: [V][W][H] float32, decoded as
+ * read_s3dis_depth_map returns them (visibility.py:1328-1358);
+ * h_params->depth_threshold is the tolerance.  Both fused entry points take at
+ * most 480 views per call.  counters[0] <- Vw, [2] <- 1 if out_capacity was
+ * exceeded, [3] <- number of views with at least one mapping.
+ * ---------------------------------------------------------------------- */
+size_t mvf_map_images_depth_workspace_bytes(int64_t num_points, int32_t V);
+int mvf_map_images_depth(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points,
+    const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
+    int32_t cylinder, const uint8_t *mask, const float *depth_maps,
+    const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, int64_t *pointers, int64_t *images,
+    int16_t *pixels, float *features, int64_t out_capacity, int32_t *view_seen,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * torch_scatter.segment_csr(src, ptr, reduce) on dim 0 of a [rows][C] float32
  * matrix (modules/multimodal/pooling.py:63 and :289,295,519,525,628,799,819,
  * 863; core/multimodal/image.py:1777).  out: [nseg][C]; empty segment -> 0;

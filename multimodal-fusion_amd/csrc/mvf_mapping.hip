@@ -956,19 +956,52 @@ __global__ __launch_bounds__(256) void mi_centre_kernel(
 
 struct PixelXform { int up, down, crop_w, crop_h; };
 
-// Shared by the count and the fill pass: does the seen point position i keep
-// its mapping in view v, and at which (converted) pixel?  0 = not mapped, 1 =
+// The kernels of the fused paths keep the views of a call in LDS (128 bytes each).
+constexpr int MI_MAX_VIEWS = 480;
+
+// Which (point, view) pairs the visibility model keeps.  `candidates`: bit mask
+// of the views [32 wd, 32 wd + 32) worth testing for point position i;
+// `keeps`: the model's verdict for a pair that passed the projection.
+struct SplatKeep {
+    // exact splat visibility: candidates are the winners of the z-buffer, kept is
+    // who holds its centre pixel (visibility.py:1168-1187)
+    const uint8_t *seen; i64 seen_stride; CentreTable table; int Hc;
+    __device__ unsigned candidates(i64 i, int wd, int V) const {
+        unsigned sm = seen_chunk(seen, seen_stride, i, 2 * wd);
+        if (32 * wd + 16 < V) sm |= seen_chunk(seen, seen_stride, i, 2 * wd + 1) << 16;
+        return sm;
+    }
+    __device__ bool keeps(const mvf_vis_params &P, i64 i, int v, int cx, int cy, float) const {
+        return centre_lookup(table, centre_pixel_id(v, cx, cy - P.crop_top, P.W, Hc)) == (unsigned)i + 1u;
+    }
+};
+struct DepthKeep {
+    // visibility_from_depth_map (visibility.py:1361-1388): the map's depth at the
+    // pixel is within depth_threshold of the point's distance; maps [V][W][H]
+    const float *maps;
+    __device__ unsigned candidates(i64, int wd, int V) const {
+        const int left = V - 32 * wd;
+        return left >= 32 ? 0xffffffffu : (1u << left) - 1u;
+    }
+    __device__ bool keeps(const mvf_vis_params &P, i64, int v, int cx, int cy, float dist) const {
+        const float real = maps[((size_t)v * P.W + cx) * P.H + cy];
+        return fabsf(__fsub_rn(real, dist)) <= P.depth_threshold;
+    }
+};
+
+// Shared by the count and the fill pass: does the point position i keep its
+// mapping in view v, and at which (converted) pixel?  0 = not mapped, 1 =
 // mapped by the visibility model but outside the crop (the view still counts
 // as seen, image.py:289-290,350), 2 = kept.
+template <class Keep>
 __device__ __forceinline__ int mi_survives(
-    const CloudSrc &src, const mvf_vis_params &P, int Hc,
-    const CentreTable &table, const PixelXform &X, i64 i, int v,
+    const CloudSrc &src, const mvf_vis_params &P, const Keep &keep, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
     double x, y, fx, fy;
     if (!src.get(i, v, P, x, y, dist, fx, fy)) return 0;
     const int cx = (int)x, cy = (int)y;
-    if (centre_lookup(table, centre_pixel_id(v, cx, cy - P.crop_top, P.W, Hc)) != (unsigned)i + 1u) return 0;
+    if (!keep.keeps(P, i, v, cx, cy, dist)) return 0;
     // image.py:307-319 (non-negative operands: floor division == truncation)
     px = cx / X.up - src.views[v].crop_off_x;
     py = cy / X.up - src.views[v].crop_off_y;
@@ -991,13 +1024,12 @@ __device__ __forceinline__ void mi_pixel(
     y_proj = y;
 }
 
-// Pass 1 of the CSR assembly: one thread per output point id.  Reads the seen
-// flags of its point (16 views per load), resolves centre-pixel conflicts and
-// the crop, stores the kept-view bit masks masks[word][q] and the block's
-// mapping count.
+// Pass 1 of the CSR assembly: one thread per output point id.  Tests the
+// candidate views of its point (projection, visibility model, crop), stores
+// the kept-view bit masks masks[word][q] and the block's mapping count.
+template <class Keep>
 __global__ __launch_bounds__(256) void mi_point_mask_kernel(
-    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int Hc,
-    CentreTable table, PixelXform X, int V,
+    CloudSrc src, mvf_vis_params P, Keep keep, PixelXform X, int V,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
@@ -1008,18 +1040,14 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     unsigned c = 0;
     const int words = (V + 31) >> 5;
     for (int wd = 0; wd < words; ++wd) {
-        unsigned sm = 0;
-        if (i >= 0) {
-            sm = seen_chunk(seen, seen_stride, i, 2 * wd);
-            if (32 * wd + 16 < V) sm |= seen_chunk(seen, seen_stride, i, 2 * wd + 1) << 16;
-        }
+        unsigned sm = i >= 0 ? keep.candidates(i, wd, V) : 0u;
         unsigned kept = 0;
         while (sm) {
             const int bit = __ffs(sm) - 1;
             sm &= sm - 1;
             const int v = (wd << 5) + bit;
             int px, py; float d; double yp;
-            const int s = mi_survives(src, P, Hc, table, X, i, v, px, py, d, yp);
+            const int s = mi_survives(src, P, keep, X, i, v, px, py, d, yp);
             if (s) view_seen[v] = 1;
             if (s == 2) kept |= 1u << bit;
         }
@@ -1439,8 +1467,8 @@ extern "C" int mvf_map_images_exact(
 {
     (void)point_ids;
     if (int rc = check_params(h_params, "map_images_exact")) return rc;
-    MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= 65535,
-                "map_images_exact: bad sizes n=%lld V=%d", (long long)n, V);
+    MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= MI_MAX_VIEWS,
+                "map_images_exact: bad sizes n=%lld V=%d (at most %d views per call)", (long long)n, V, MI_MAX_VIEWS);
     MVF_REQUIRE(xyz && inv_ids && views && pointers && images && pixels && features &&
                 view_seen && counters, "map_images_exact: null buffer");
     MVF_REQUIRE(proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 &&
@@ -1509,9 +1537,67 @@ extern "C" int mvf_map_images_exact(
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
-    hipLaunchKernelGGL(mi_point_mask_kernel, grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, Hc,
-                       table, X, V, (const i64 *)inv_ids, (i64)num_points,
+    hipLaunchKernelGGL((mi_point_mask_kernel<SplatKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
+                       SplatKeep{seen, seen_stride, table, Hc}, X, V, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
+    prof_mark("point_mask", st);
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
+                       (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
+                       feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
+                       (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
+                       (i64 *)counters);
+    prof_mark("csr_fill", st);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// MapImages with DepthBasedVisibility, all views in one launch set: no z-buffer
+// and no shared-pixel rule, so the pass is the CSR assembly alone with the
+// depth-map test as the visibility model.
+extern "C" size_t mvf_map_images_depth_workspace_bytes(int64_t num_points, int32_t V)
+{
+    const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
+    const size_t words = (size_t)(V + 31) / 32;
+    return align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned)) +
+           align_up(nb * sizeof(unsigned));
+}
+
+extern "C" int mvf_map_images_depth(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
+    int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *depth_maps, const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t proj_upscale, int32_t downscale, int32_t crop_w, int32_t crop_h,
+    int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_params(h_params, "map_images_depth")) return rc;
+    MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= MI_MAX_VIEWS,
+                "map_images_depth: bad sizes n=%lld V=%d (at most %d views per call)", (long long)n, V, MI_MAX_VIEWS);
+    MVF_REQUIRE(xyz && inv_ids && views && depth_maps && pointers && images && pixels && features &&
+                view_seen && counters, "map_images_depth: null buffer");
+    MVF_REQUIRE(proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 && out_capacity >= 0,
+                "map_images_depth: bad scalar argument");
+    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
+                "map_images_depth: pinhole cameras only");
+    const mvf_vis_params P = *h_params;
+    hipStream_t st = (hipStream_t)stream;
+    const i64 nb = cdiv(num_points, 256);
+    const int words = (V + 31) / 32;
+    Arena ar(workspace, workspace_bytes);
+    unsigned *masks = ar.take<unsigned>((size_t)words * num_points);
+    unsigned *block_sums = ar.take<unsigned>(nb);
+    if (!ar.ok()) { set_error("map_images_depth: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
+
+    prof_begin(st);
+    MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
+    MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int32_t), st));
+    prof_mark("memset", st);
+    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
+    PixelXform X{proj_upscale, downscale, crop_w, crop_h};
+    dim3 grid_q((unsigned)nb), block(256);
+    hipLaunchKernelGGL((mi_point_mask_kernel<DepthKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
+                       DepthKeep{depth_maps}, X, V, (const i64 *)inv_ids, (i64)num_points, masks, block_sums,
+                       view_seen);
     prof_mark("point_mask", st);
     hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,

@@ -97,6 +97,18 @@ def pack_views(images, camera):
     return torch.from_numpy(buf)
 
 
+def _stack_depth_maps(images, device):
+    """[V, W, H] float32 device tensor of the decoded depth maps of the views
+    (a list of [W, H] maps, or the stacked tensor itself)."""
+    dm = images.depth_maps
+    if not torch.is_tensor(dm):
+        dm = torch.stack([torch.as_tensor(d) for d in dm])
+    dm = dm.to(device=device, dtype=torch.float32).contiguous()
+    assert tuple(dm.shape) == (images.num_views,) + tuple(images.proj_size), \
+        f"depth maps must be [V, W, H] = {(images.num_views,) + tuple(images.proj_size)}"
+    return dm
+
+
 class FusedMapPlan:
     """One sample staged on the device for ``mvf_map_images_exact`` plus the
     output / workspace buffers, which are reused from run to run and grown when
@@ -113,8 +125,11 @@ class FusedMapPlan:
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
-                 lane=0, centre_slots=None):
+                 lane=0, centre_slots=None, depth_maps=None):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
+        # [V, W, H] float32 depth maps: the pass then runs DepthBasedVisibility
+        # (mvf_map_images_depth) instead of the exact splat visibility
+        self.depth_maps = depth_maps
         self.views, self.mask, self.params = views, mask, params
         self.cylinder, self.upscale, self.downscale, self.crop_size = \
             cylinder, upscale, downscale, crop_size
@@ -138,7 +153,7 @@ class FusedMapPlan:
             self.pos, self.ids, self.inv, self.attrs, self.views, self.mask, self.params,
             self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
             self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane,
-            centre_slots=self.centre_slots)
+            centre_slots=self.centre_slots, depth_maps=self.depth_maps)
 
     def _slot(self, k):
         """Output buffers of slot k: (out_cap, counters, host counters, event,
@@ -163,9 +178,12 @@ class FusedMapPlan:
         key = (self.pair_cap, self.centre_slots)
         if self._ws is None or self._ws[0] != key:
             lib = L.load()
-            ws_bytes = lib.mvf_map_images_workspace_bytes(
-                self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
-                self.centre_slots)
+            if self.depth_maps is not None:
+                ws_bytes = lib.mvf_map_images_depth_workspace_bytes(self.num_points, self.V)
+            else:
+                ws_bytes = lib.mvf_map_images_workspace_bytes(
+                    self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
+                    self.centre_slots)
             self._ws = (key, L.workspace(ws_bytes, self.device))
         return self._ws[1]
 
@@ -177,6 +195,17 @@ class FusedMapPlan:
         sl = self._slot(slot)
         _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = sl
         ws = self._workspace()
+        if self.depth_maps is not None:
+            with torch.cuda.device(self.device):
+                L.check(lib.mvf_map_images_depth(
+                    L.ptr(self.pos), L.ptr(self.inv), self.N, self.num_points,
+                    L.ptr(self.views), self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
+                    L.ptr(self.depth_maps), *[L.ptr(a) for a in self.attrs], self.upscale,
+                    self.downscale, int(self.crop_size[0]), int(self.crop_size[1]),
+                    L.ptr(pointers), L.ptr(img_ids), L.ptr(pixels), L.ptr(feats), self.out_cap,
+                    L.ptr(view_seen), L.ptr(counters), L.ptr(ws), ws.numel(),
+                    L.stream_ptr(self.device)))
+            return sl
         with torch.cuda.device(self.device):
             L.check(lib.mvf_map_images_exact(
                 L.ptr(self.pos), L.ptr(self.ids), L.ptr(self.inv), self.N, self.num_points,
@@ -292,13 +321,21 @@ class MapImages(ImageTransform):
         return kdtree_order(data.pos, self.cylinder)
 
     def _fusable(self, images, visi_model):
+        """Can all views of these images go through one launch set?  Exact splat
+        visibility or depth-map visibility (with the decoded maps at hand as
+        ``images.depth_maps``), pinhole cameras, integer scale factors."""
         ints = all(float(s).is_integer() and s >= 1
                    for s in (images.proj_upscale, images.downscale))
-        return (self.method == 'SplattingVisibility' and bool(visi_model.exact)
-                and visi_model.camera in ('kitti360_perspective', 'scannet')
-                and ints and images.pixel_dtype == torch.int16
-                and images.is_pinhole and images.has_extrinsic
-                and images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1)
+        common = (visi_model.camera in ('kitti360_perspective', 'scannet')
+                  and ints and images.pixel_dtype == torch.int16
+                  and images.is_pinhole and images.has_extrinsic
+                  and images.num_views <= 480)
+        if self.method == 'SplattingVisibility':
+            return (common and bool(visi_model.exact)
+                    and images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1)
+        if self.method == 'DepthBasedVisibility':
+            return common and getattr(images, 'depth_maps', None) is not None
+        return False
 
     def _settle(self, data, images):
         """Checks and image settings of image.py:192-215; returns the
@@ -404,7 +441,9 @@ class MapImages(ImageTransform):
         into the sampler's order, mapping ids and their inverse, packed views.
         Returns a FusedMapPlan, or None when mapping ids repeat."""
         N = data.pos.shape[0]
-        order = self._order(data)
+        depth = self.method == 'DepthBasedVisibility'
+        # the depth test has no ties: any point order gives the same mappings
+        order = None if depth else self._order(data)
         ids = getattr(data, self.key).to(device=device, dtype=torch.int64)
         pos = data.pos.to(device=device, dtype=torch.float32)
         attrs = [getattr(data, k, None) for k in ('linearity', 'planarity', 'scattering', 'norm')]
@@ -427,7 +466,8 @@ class MapImages(ImageTransform):
             visibility_module.make_params(**visi_model.__dict__), bool(self.cylinder),
             int(images.proj_upscale), int(images.downscale), tuple(images.crop_size),
             images.num_views, num_points, device, self._pair_cap, self._out_cap,
-            centre_slots=self._centre_slots)
+            centre_slots=self._centre_slots,
+            depth_maps=_stack_depth_maps(images, device) if depth else None)
 
     def _process_fused(self, data, images, visi_model, device):
         plan = self.prepare_fused(data, images, visi_model, device)

@@ -220,6 +220,34 @@ def read_s3dis_depth_map(path, img_size=None, empty=-1):
     return out
 
 
+def render_depth_maps(xyz, img_pos, img_intrinsic_pinhole, img_extrinsic, img_size, r_max=30,
+                      r_min=0.5, voxel=0.1, k_swell=1.0, d_swell=1000,
+                      camera='kitti360_perspective', quantum=1.0 / 512):
+    """Depth maps [V, W, H] float32 of a cloud seen from V pinhole views, in the
+    format ``read_s3dis_depth_map`` returns (visibility.py:1328-1358): the
+    distance of the nearest splat per pixel (non-exact splat visibility of this
+    library), rounded to ``quantum`` metres as the 16-bit PNGs are, -1 where no
+    splat lands.  For synthetic inputs of the depth-map visibility model."""
+    device = L.require_device(xyz)
+    xyz_d = _dev(xyz, device, torch.float32)
+    W, H = int(img_size[0]), int(img_size[1])
+    V = img_pos.shape[0]
+    out = torch.full((V, W, H), -1.0, dtype=torch.float32, device=device)
+    for v in range(V):
+        idx, dist, x, y = camera_projection(
+            xyz_d, img_pos[v].float(), img_intrinsic_pinhole=img_intrinsic_pinhole[v],
+            img_extrinsic=img_extrinsic[v], img_size=(W, H), r_max=r_max, r_min=r_min,
+            camera=camera)
+        if idx.shape[0] == 0:
+            continue
+        vi, px, py = visibility_from_splatting(
+            x, y, dist, None, img_intrinsic_pinhole=img_intrinsic_pinhole[v], img_size=(W, H),
+            voxel=voxel, k_swell=k_swell, d_swell=d_swell, exact=False, camera=camera)
+        d = torch.round(dist[vi].double() / quantum) * quantum
+        out[v, px, py] = d.float()
+    return out
+
+
 def visibility_from_depth_map(
         x_proj, y_proj, dist, depth_map_path=None, img_size=(1024, 512),
         depth_threshold=0.05, depth_map=None, **kwargs):

@@ -82,6 +82,49 @@ def test_c5_depth_map_visibility_full_size():
     check_mapping(out.mappings, want)
 
 
+def test_c5_fused_depth_map_16_views_with_pools():
+    """The per-GPU share of the dense scene: 2 M points, 16 views of 4 MP,
+    depth-map visibility for all views in one launch set (no per-view loop),
+    then the pixel -> view -> point pools; mapping bit-exact against the
+    oracle's per-view loop, pools against its segment reductions."""
+    from mvfusion.pooling import segment_csr_two_level
+    from mvfusion.transforms import MapImages
+    from mvfusion.visibility import render_depth_maps
+    V, C_feat = 16, 8
+    sc = S.make_scene("c5", seed=4, n_views=V)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    W, H = sc["img_size"]
+    assert N == 2_000_000 and (W, H) == (2304, 1728)
+    K = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = sc["fx"], sc["fy"], sc["mx"], sc["my"]
+    kw = {k: VIS[k] for k in ("voxel", "k_swell", "d_swell", "camera", "r_max", "r_min")}
+    dm = render_depth_maps(T(xyz).to(DEV), T(sc["pos"]), T(K), T(sc["extrinsic"]), (W, H), **kw)
+    dm_host = dm.cpu().numpy()
+    vis = {k: VIS[k] for k in ("r_max", "r_min", "camera")}
+    want = orc.map_images(xyz, np.arange(N), sc, order=None, method="depth_map", ref_size=(W, H),
+                          cylinder=True, depth_maps=dm_host, depth_threshold=0.05, **vis)
+    data, images = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=False)
+    images.depth_maps = dm
+    t = MapImages(method="DepthBasedVisibility", cylinder=True, depth_threshold=0.05, **vis)
+    model = t._settle(data, images)
+    assert t._fusable(images, model)
+    _, out = t(data, images)
+    m = out.mappings
+    assert m.images.shape[0] > 500_000
+    check_mapping(m, want)
+    # pools: one pixel per (point, view); pixel -> view max, view -> point max and mean
+    rng = np.random.default_rng(5)
+    Pn = m.images.shape[0]
+    x_pix = rng.random((Pn, C_feat), dtype=np.float32)
+    atomic_ptr = torch.arange(Pn + 1, dtype=torch.int64, device=DEV)
+    g_max, g_mean = segment_csr_two_level(T(x_pix).to(DEV), atomic_ptr, m.pointers.to(DEV),
+                                          inner="max", outer=("max", "mean"))
+    xv = orc.segment_csr(x_pix, want["view_pointers"], "max")
+    assert np.array_equal(npy(g_max), orc.segment_csr(xv, want["pointers"], "max"))
+    np.testing.assert_allclose(npy(g_mean), orc.segment_csr(xv, want["pointers"], "mean"), rtol=1e-5, atol=0)
+
+
 def test_c4_batch_of_cylinders():
     """Per-GPU share of the 64-cylinder batch: every cylinder mapped on its own,
     the mappings concatenated (csr.py:347-416, image.py:1627-1682), pixel
