@@ -1,12 +1,23 @@
 """Benchmark of the multi-view image->point fusion hot path on MI355X.
 
-One "step" = one pass of the hot path over one sample resident in HBM:
-fused MapImages (projection + splat z-buffer visibility + CSR assembly for all
-views) followed by the atomic (pixel->view, max) and view (view->point, max and
-mean) CSR pools.  Metric: points x views mapped+fused per second (whole job, all
-ranks).  With N > 1 ranks every rank maps and pools its own sample (weak
-scaling) and the pooled features + labels are gathered once over RCCL at the
-end of the timed region.
+One "step" = one pass of the hot path over one sample (or one rank's batch of
+samples) resident in HBM: MapImages for all views (projection, visibility,
+CSR assembly) followed by the atomic (pixel->view, max) and view (view->point,
+max and mean) CSR pools.  Metric: points x views mapped+fused per second (whole
+job, all ranks).  With N > 1 ranks every rank maps and pools its own sample
+(weak scaling) and the pooled features + labels are gathered once over RCCL at
+the end of the timed region.
+
+Workloads (--config):
+  c2  WildScenes-shaped scan, 300k pts x 16 views 2016x1512, exact splat visibility   (headline)
+  c1  KITTI-360-shaped cylinder, 100k pts x 8 views 1408x376, exact splat visibility
+  c3  QKVBimodalCSRPool forward, 500k pts x <= 32 views
+  c4  a rank's share of the 64-cylinder batch: 8 x c1, mapped on 3 streams, one ImageMappingBatch, pooled at once
+  c5  a rank's share of the dense scene: 2M pts x 16 (--views) views of 4 MP, depth-map visibility
+
+The default run (c2) also runs short versions of the other workloads and a
+wall-clock measurement of MapImages.__call__ from host tensors; they are nested
+in the one JSON line under "other_workloads" and "end_to_end".
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -34,13 +45,21 @@ from mvfusion.distributed import gather_pooled           # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec peak
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, dense fp32-input MFMA (v_mfma_f32_32x32x2_f32)
+# LDS atomic-minimum issue cost: 6.58 cycles per 64-bit wave-instruction per CU at the
+# 2.4 GHz the cycle count was taken at (profiles/microbench/lds_ops_bench.hip), 256 CUs
+LDS_ATOMIC_PEAK = 256 * 2.4e9 / 6.58          # wave-instructions / s
 VIS = dict(voxel=0.05, r_max=20, r_min=0, k_swell=1.5, d_swell=1e6, exact=True,
            camera="kitti360_perspective")
 WORKLOADS = {
-    "c1": dict(channels=64, label="KITTI-360-shaped cylinder, 100k pts x 8 views 1408x376"),
-    "c2": dict(channels=13, label="WildScenes-shaped scan, 300k pts x 16 views 2016x1512"),
+    "c1": dict(scene="c1", channels=64, label="KITTI-360-shaped cylinder, 100k pts x 8 views 1408x376"),
+    "c2": dict(scene="c2", channels=13, label="WildScenes-shaped scan, 300k pts x 16 views 2016x1512"),
     "c3": dict(channels=64, label="QKVBimodalCSRPool, 500k pts x <=32 views (Poisson 4), "
                                   "64-ch modality, 32-ch main, 8-ch mapping features, 16-ch keys"),
+    "c4": dict(scene="c1", channels=64, samples=8,
+               label="one rank's share of the 64-cylinder batch: 8 KITTI-360-shaped cylinders "
+                     "(100k pts x 8 views 1408x376 each), one ImageMappingBatch"),
+    "c5": dict(scene="c5", channels=64, label="one rank's share of the dense scene: 2M pts x 4 MP views, "
+                                              "depth-map visibility"),
 }
 
 
@@ -48,32 +67,52 @@ class Data:
     pass
 
 
-def stage_sample(cfg, seed, device):
-    """Build one synthetic sample on the host and stage it in HBM."""
-    sc = S.make_scene(cfg, seed=seed)
+def host_sample(scene, seed, n_views=None):
+    """Synthetic sample as the host tensors a data loader would hand over."""
+    kw = {} if n_views is None else dict(n_views=n_views)
+    sc = S.make_scene(scene, seed=seed, **kw)
     N = sc["xyz"].shape[0]
     T = torch.from_numpy
     data = Data()
     data.pos = T(sc["xyz"])
     data.mapping_index = torch.arange(N)
-    data.mvf_point_order = kdtree_order(data.pos, True)
     images = SameSettingImageData(
         pos=T(sc["pos"]), extrinsic=T(sc["extrinsic"]), fx=T(sc["fx"]), fy=T(sc["fy"]),
         mx=T(sc["mx"]), my=T(sc["my"]), ref_size=sc["img_size"], proj_upscale=1)
-    t = MapImages(method="SplattingVisibility", cylinder=True, **VIS)
-    model = visibility_module.SplattingVisibility(img_size=images.proj_size, **VIS)
+    return sc, data, images
+
+
+def stage_sample(scene, seed, device, depth=False, n_views=None):
+    """Build one synthetic sample on the host and stage it in HBM."""
+    sc, data, images = host_sample(scene, seed, n_views)
+    if depth:
+        V = sc["pos"].shape[0]
+        K = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
+        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = sc["fx"], sc["fy"], sc["mx"], sc["my"]
+        kw = {k: VIS[k] for k in ("voxel", "k_swell", "d_swell", "camera", "r_max", "r_min")}
+        images.depth_maps = visibility_module.render_depth_maps(
+            data.pos.to(device), images.pos, torch.from_numpy(K), images.extrinsic, sc["img_size"], **kw)
+        vis = {k: VIS[k] for k in ("r_max", "r_min", "camera")}
+        t = MapImages(method="DepthBasedVisibility", cylinder=True, depth_threshold=0.05, **vis)
+        model = visibility_module.DepthBasedVisibility(img_size=images.proj_size, depth_threshold=0.05, **vis)
+    else:
+        data.mvf_point_order = kdtree_order(data.pos, True)
+        t = MapImages(method="SplattingVisibility", cylinder=True, **VIS)
+        model = visibility_module.SplattingVisibility(img_size=images.proj_size, **VIS)
     plan = t.prepare_fused(data, images, model, device)
     return sc, plan
 
 
-def algorithmic_bytes(N, V, W, Hc, M, F, C):
+def algorithmic_bytes(N, V, W, Hc, M, F, C, depth=False, m_fov=0):
     """Closed-form byte model: xyz read once per view, one write + one read of
-    an 8-byte z-buffer cell per pixel, the emitted mappings, the output CSR,
-    and each pool reading its input once and writing its output once."""
+    an 8-byte z-buffer cell per pixel (splat visibility) or one 4-byte depth
+    gather per in-view point (depth-map visibility), the emitted mappings, the
+    output CSR, and each pool reading its input once and writing its output
+    once."""
     Vw = P = M
     b = {}
     b["projection"] = V * 12 * N
-    b["zbuffer"] = V * 16 * W * Hc
+    b["zbuffer"] = 4 * m_fov if depth else V * 16 * W * Hc
     b["emit"] = M * (8 + 4 + 4 + 4 * F)
     b["csr"] = 8 * (N + 1) + 8 * Vw + 8 * (Vw + 1) + 4 * P + 4 * F * Vw
     b["atomic_pool"] = 4 * C * P + 4 * C * Vw + 8 * (Vw + 1)
@@ -83,17 +122,16 @@ def algorithmic_bytes(N, V, W, Hc, M, F, C):
     return b
 
 
-# stage of mvf_map_images_exact -> share of the byte model it is charged with
-STAGE_BYTES = {
-    "bin_count": "projection", "tile_zbuffer": "zbuffer", "csr_fill": "emit+csr",
-}
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mvf_oracle as orc
+    return orc
 
 
 def cpu_baseline(cfg, C_feat, target_s=12.0):
     """The CPU oracle (single-threaded C + numpy port of the reference's CPU
     algorithm) on the same workload, timed on this host."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import mvf_oracle as orc
+    orc = oracle()
     sc = S.make_scene(cfg, seed=2)
     N, V = sc["xyz"].shape[0], sc["pos"].shape[0]
     order = kdtree_order(torch.from_numpy(sc["xyz"]), True).numpy()
@@ -147,6 +185,14 @@ def cpu_model():
     return "unknown"
 
 
+def pmc_traffic(cfg, key):
+    """Measured HBM bytes per launch (rocprofv3 PMC passes, profiles/pmc_traffic.json)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        return json.load(open(tpath)).get(cfg, {}).get(key)
+    return None
+
+
 def qkv_flops(N, Vw, F_main, F_map, C, D, G, inner=32):
     """Multiply-adds x 2 of QKVBimodalCSRPool.forward (pooling.py:454-547) with a
     DeepSetFeat map encoder: E_main, Q on N rows; mlp_elt_1, mlp_elt_2, E_mod, K,
@@ -157,7 +203,27 @@ def qkv_flops(N, Vw, F_main, F_map, C, D, G, inner=32):
     return 2 * (N * per_point + Vw * per_view)
 
 
-def run_qkv(args, rank, world, device, dist):
+class Timer:
+    """Barrier + synchronize on both sides of a timed region, max over ranks."""
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def elapsed(self, t0):
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+
+def run_qkv(args, rank, world, device, dist, cpu_leg=True):
     """C3: the attentive pool on synthetic CSR groups; one step = one forward."""
     from mvfusion import pooling
     N, F_main, F_map, Cm, D, G = 500_000, 32, 8, 64, 16, 1
@@ -173,11 +239,7 @@ def run_qkv(args, rank, world, device, dist):
     torch.manual_seed(0)
     mod = pooling.QKVBimodalCSRPool(in_main=F_main, in_map=F_map, in_mod=Cm, out_mod=Cm,
                                     nc_qk=D, num_groups=G).to(device).eval()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    tm = Timer(dist, device)
 
     # consecutive forwards are independent: they alternate between streams so
     # that the matrix-core-bound launches of one overlap the HBM-bound ones of
@@ -190,9 +252,10 @@ def run_qkv(args, rank, world, device, dist):
         cur = torch.cuda.current_stream(device)
         for s in streams:
             s.wait_stream(cur)
-        for j in range(k):
-            with torch.cuda.stream(streams[j % n_lanes]):
-                out = mod(x_main, x_mod, x_map, ptr)
+        with torch.no_grad():
+            for j in range(k):
+                with torch.cuda.stream(streams[j % n_lanes]):
+                    out = mod(x_main, x_mod, x_map, ptr)
         for s in streams:
             cur.wait_stream(s)
         return out
@@ -201,32 +264,26 @@ def run_qkv(args, rank, world, device, dist):
     if dist is not None and out is not None:
         # untimed: the first collective of each kind sets up its RCCL channels
         gather_pooled(out, labels)
-    barrier()
+    tm.barrier()
     t0 = time.perf_counter()
     out = forwards(args.steps)
     if dist is not None:
         gather_pooled(out, labels)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    tm.barrier()
+    elapsed = tm.elapsed(t0)
     if rank != 0:
-        return
+        return None
     # launch duration of the whole forward with HIP events on the launch stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
-    for _ in range(args.steps):
-        mod(x_main, x_mod, x_map, ptr)
+    with torch.no_grad():
+        for _ in range(args.steps):
+            mod(x_main, x_mod, x_map, ptr)
     ev[1].record()
     torch.cuda.synchronize()
     fwd_ms = ev[0].elapsed_time(ev[1]) / args.steps
     flops = qkv_flops(N, Vw, F_main, F_map, Cm, D, G)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("c3", {}).get("forward")
+    traffic = pmc_traffic("c3", "forward")
     bytes_ = 4 * (F_main * N + (Cm + F_map) * Vw + Cm * N) + 8 * (N + 1)
     line = {
         "metric": "points*views mapped+fused/sec",
@@ -240,17 +297,18 @@ def run_qkv(args, rank, world, device, dist):
         "roofline": {"bound": "mfma", "kernel": "QKVBimodalCSRPool.forward (all launches)",
                      "achieved": flops / (fwd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12,
                      "unit": "TFLOP/s", "frac": flops / (fwd_ms * 1e-3) / MFMA_F32_PEAK,
-                     "traffic": traffic, "flops_per_launch": flops, "kernel_ms": fwd_ms,
+                     "traffic": traffic,
+                     "traffic_ratio": None if traffic is None else traffic / bytes_,
+                     "flops_per_launch": flops, "kernel_ms": fwd_ms,
                      "overlapped": {"ms_per_forward": elapsed / args.steps * 1e3,
                                     "achieved": flops / (elapsed / args.steps) / 1e12,
                                     "frac": flops / (elapsed / args.steps) / MFMA_F32_PEAK},
                      "hbm": {"algorithmic_bytes": bytes_,
                              "frac": bytes_ / (fwd_ms * 1e-3) / HBM_PEAK}},
     }
-    if not args.no_cpu_baseline:
+    if cpu_leg:
         # the oracle's numpy restatement of the same forward on the first 50k points
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import mvf_oracle as orc
+        orc = oracle()
         n_cpu = 50_000
         rows_cpu = int(ptr[n_cpu])
         sd = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
@@ -267,7 +325,279 @@ def run_qkv(args, rank, world, device, dist):
             "value": rows_cpu / sorted(ts)[1], "unit": "points*views/s", "cores": 1, "kind": "port",
             "sample": f"oracle QKV forward on the first {n_cpu} points ({rows_cpu} rows) of the same "
                       f"workload, median of 3: {sorted(ts)[1]:.3f} s; GPU output matches it to {err:.1e} (rel. to max)"}
-    print(json.dumps(line))
+    return line
+
+
+def zbuffer_ops(plan):
+    """LDS atomic work of the z-buffer pass of the plan's last launch: wave-level
+    atomic instructions, lane-level atomics, (splat, tile) entries."""
+    lib = L.load()
+    out = torch.zeros(3, dtype=torch.int64, device=plan.device)
+    ws = plan._workspace()
+    with torch.cuda.device(plan.device):
+        L.check(lib.mvf_profile_zbuffer_ops(
+            L.ptr(ws), ws.numel(), plan.N, plan.V, C.byref(plan.params), plan.num_points,
+            plan.pair_cap, plan.centre_slots, L.ptr(out), L.stream_ptr(plan.device)))
+    return [int(v) for v in out.tolist()]
+
+
+def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
+    """C1 / C2 / C5 (one sample per step) and C4 (a batch of samples per step):
+    fused MapImages + the pixel -> view -> point pools."""
+    from mvfusion.mapping import ImageMapping, ImageMappingBatch
+    wl = WORKLOADS[cfg]
+    C_feat = wl["channels"]
+    depth = cfg == "c5"
+    n_samples = wl.get("samples", 1)
+    n_views = args.views if depth else None
+    staged = [stage_sample(wl["scene"], seed=2 + rank * n_samples + k, device=device, depth=depth,
+                           n_views=n_views) for k in range(n_samples)]
+    sc, plan = staged[0]
+    N, V = plan.N, plan.V
+    W, H = sc["img_size"]
+    N_all = sum(p.N for _, p in staged)
+    gen = torch.Generator(device=device).manual_seed(rank)
+    labels = torch.randint(0, 19, (N_all,), device=device, generator=gen)
+    # pixel features for every possible mapping row, resident in HBM
+    for _, p in staged:
+        p.run()
+    cap = sum(p.out_cap for _, p in staged)
+    x_pix = torch.rand((cap, C_feat), device=device, generator=gen)
+    atomic_ptr = torch.arange(cap + 1, dtype=torch.int64, device=device)
+    lib = L.load()
+    tm = Timer(dist, device)
+
+    def pools(pointers, n_rows):
+        # pixel -> view max, then view -> point max and mean, in one pass over x_pix
+        return segment_csr_two_level(x_pix[:n_rows], atomic_ptr[:n_rows + 1], pointers,
+                                     inner="max", outer=("max", "mean"))
+
+    # Consecutive samples are independent: they alternate between streams (each
+    # with its own plan: outputs and workspace), so that the latency-bound
+    # kernels of one pass overlap with another pass's.  On each stream the
+    # mapping pass of the next sample is enqueued before the sizes of the
+    # current one are waited for, so the device does not idle on the host
+    # round trip.
+    n_lanes = max(1, args.lanes)
+    streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
+    if n_samples == 1:
+        plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
+    else:
+        plans = [p for _, p in staged]
+        for k, p in enumerate(plans):
+            p.lane = k % n_lanes
+    # set-up: every plan allocates its outputs and workspace once
+    for k, p_ in enumerate(plans):
+        with torch.cuda.stream(streams[k % n_lanes]):
+            p_.run()
+    torch.cuda.synchronize()
+
+    def run_steps_single(k):
+        """k full steps (mapping pass, size read-back, pools each)."""
+        out = None
+        pending = [None] * n_lanes
+        cur = torch.cuda.current_stream(device)
+        for s in streams:
+            s.wait_stream(cur)
+        for j in range(min(n_lanes, k)):
+            with torch.cuda.stream(streams[j]):
+                pending[j] = plans[j].run_async()
+        for j in range(k):
+            ln = j % n_lanes
+            with torch.cuda.stream(streams[ln]):
+                nxt = plans[ln].run_async() if j + n_lanes < k else None
+                pointers, img_ids, _, _, _ = pending[ln].result()
+                out = pools(pointers, img_ids.shape[0])
+                pending[ln] = nxt
+        for s in streams:
+            cur.wait_stream(s)
+        return out
+
+    def run_steps_batch(k):
+        """k steps of: map every sample of the batch (spread over the streams),
+        concatenate the mappings into one ImageMappingBatch (csr.py:347-416,
+        image.py:1627-1682), pool the whole batch in one launch.  The mapping
+        passes of the next step are enqueued before the current step's sizes
+        are waited for (every plan alternates between two output sets)."""
+        out = None
+        cur = torch.cuda.current_stream(device)
+        pool_stream = streams[0]
+
+        def enqueue():
+            pend = []
+            for p in plans:
+                with torch.cuda.stream(streams[p.lane]):
+                    pend.append(p.run_async())
+            return pend
+
+        for s in streams:
+            s.wait_stream(cur)
+        pend = enqueue() if k > 0 else None
+        for j in range(k):
+            nxt = enqueue() if j + 1 < k else None
+            maps = []
+            for p, pd in zip(plans, pend):
+                with torch.cuda.stream(streams[p.lane]):
+                    pointers, img_ids, pixels, feats, _ = pd.result()
+                maps.append(ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats))
+            # result() has waited for every pass of this step: the pools may read them
+            with torch.cuda.stream(pool_stream):
+                batch = ImageMappingBatch.from_csr_list(maps)
+                out = pools(batch.view_csr_indexing, batch.images.shape[0])
+            pend = nxt
+        for s in streams:
+            cur.wait_stream(s)
+        return out
+
+    run_steps = run_steps_single if n_samples == 1 else run_steps_batch
+    out = run_steps(args.warmup) if args.warmup > 0 else None
+    if dist is not None and out is not None:
+        # untimed: the first collective of each kind sets up its RCCL channels
+        gather_pooled(torch.cat(out[:2], dim=1), labels)
+    tm.barrier()
+    t0 = time.perf_counter()
+    out = run_steps(args.steps)
+    if dist is not None:
+        # the path's only exchange: final gather of pooled features and labels
+        gather_pooled(torch.cat(out[:2], dim=1), labels)
+    tm.barrier()
+    elapsed = tm.elapsed(t0)
+    if rank != 0:
+        return None
+
+    # ---- per-kernel timing with HIP events on the launch stream (rank 0) ----
+    lib.mvf_profile_enable(1)
+    ms = (C.c_float * 16)()
+    names = (C.c_char_p * 16)()
+    stages = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    n_prof = min(args.steps, 50)
+    for _ in range(n_prof):
+        pointers, img_ids, pixels, feats, view_seen = plan.run()
+        n = lib.mvf_profile_read(ms, names, 16)
+        for i in range(n):
+            k = names[i].decode()
+            stages[k] = stages.get(k, 0.0) + ms[i]
+        P = img_ids.shape[0]
+        ev[0].record()
+        pools(pointers, P)
+        ev[1].record()
+        torch.cuda.synchronize()
+        stages["pools"] = stages.get("pools", 0.0) + ev[0].elapsed_time(ev[1])
+    lib.mvf_profile_enable(0)
+    stages = {k: v / n_prof for k, v in stages.items()}          # ms per sample
+    M = plan.last_counts["mappings"]
+    # depth-map visibility: one depth gather per in-view (point, view) pair; the
+    # pairs that pass the test are a lower bound of those that reach it
+    B = algorithmic_bytes(N, V, W, H, M, plan.F, C_feat, depth=depth, m_fov=M)
+    if depth:
+        charged = {"point_mask": B["projection"] + B["zbuffer"], "csr_fill": B["emit"] + B["csr"],
+                   "pools": B["atomic_pool"] + B["view_pool"]}
+    else:
+        charged = {"bin_count": B["projection"], "tile_zbuffer": B["zbuffer"],
+                   "csr_fill": B["emit"] + B["csr"], "pools": B["atomic_pool"] + B["view_pool"]}
+    charged = {k: v for k, v in charged.items() if k in stages}
+    dom = max(charged, key=lambda k: stages.get(k, 0.0))
+    ach = charged[dom] / (stages[dom] * 1e-3)
+    traffic = pmc_traffic(cfg, dom)
+    step_traffic = pmc_traffic(cfg, "step")
+    ms_step = elapsed / args.steps * 1e3
+    roofline = dict(
+        bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+        frac=ach / HBM_PEAK, traffic=traffic,
+        traffic_ratio=None if traffic is None else traffic / charged[dom],
+        algorithmic_bytes_per_launch=charged[dom], kernel_ms=stages[dom],
+        pipeline=dict(
+            algorithmic_bytes_per_step=B["total"] * n_samples, ms_per_step=ms_step,
+            achieved=B["total"] * n_samples / (ms_step * 1e-3) / 1e9,
+            frac=B["total"] * n_samples / (ms_step * 1e-3) / HBM_PEAK,
+            measured_traffic_per_step=step_traffic,
+            measured_frac=None if step_traffic is None
+            else step_traffic * n_samples / (ms_step * 1e-3) / HBM_PEAK),
+        stage_ms={k: round(v, 4) for k, v in stages.items()})
+    if not depth:
+        # The z-buffer lives in LDS: the byte model above charges bytes that never
+        # reach HBM.  What bounds the kernel is the issue rate of LDS atomics.
+        plan.run()
+        instr, lane_ops, entries = zbuffer_ops(plan)
+        zt = stages["tile_zbuffer"] * 1e-3
+        roofline["lds_atomic"] = dict(
+            bound="lds_atomic", kernel="tile_zbuffer", achieved=instr / zt / 1e9,
+            peak=LDS_ATOMIC_PEAK / 1e9, unit="G wave-instr/s", frac=instr / zt / LDS_ATOMIC_PEAK,
+            wave_instructions_per_launch=instr, lane_atomics_per_launch=lane_ops,
+            splat_tile_entries=entries, lanes_per_instruction=lane_ops / max(instr, 1),
+            kernel_ms=stages["tile_zbuffer"], floor_ms=instr / LDS_ATOMIC_PEAK * 1e3)
+
+    label = wl["label"]
+    if depth:
+        label += f" ({V} views per rank)"
+    line = {
+        "metric": "points*views mapped+fused/sec",
+        "value": world * N_all * V * args.steps / elapsed,
+        "unit": "points*views/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": label
+                   + (", depth-map visibility" if depth else ", exact splat visibility")
+                   + f" + max atomic pool + max/mean view pools (C={C_feat}, pools fused in one pass)",
+                   "name": cfg, "points_per_gpu": N_all, "views": V, "image": [W, H],
+                   "samples_per_step": n_samples,
+                   "mappings_per_sample": plan.last_counts["mappings"],
+                   "splat_tile_pairs": plan.last_counts["pairs"],
+                   "streams_per_gpu": n_lanes,
+                   "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
+        "roofline": roofline,
+    }
+    if cpu_leg and not depth and n_samples == 1:
+        line["cpu_baseline"] = cpu_baseline(wl["scene"], C_feat)
+    return line
+
+
+def end_to_end(cfg, device, reps=5):
+    """Wall clock of MapImages.__call__(data, images) as a data loader calls it:
+    ImageMapping on the device out (point order, staging, kernels, size
+    read-back, CSR wrap).  `cold`: first call on a sample (builds the KD-tree
+    order on the host, as the reference builds its tree); `steady`: the order
+    is cached on `data` (the reference caches the tree)."""
+    sc, data, images = host_sample(WORKLOADS[cfg]["scene"], seed=2)
+    N, V = data.pos.shape[0], images.num_views
+    t = MapImages(method="SplattingVisibility", cylinder=True, output_device=device, **VIS)
+
+    def call(d):
+        im = SameSettingImageData(
+            pos=images.pos, extrinsic=images.extrinsic, fx=images.fx, fy=images.fy, mx=images.mx,
+            my=images.my, ref_size=sc["img_size"], proj_upscale=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t(d, im)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, dict(t.timings)
+
+    host_pos = data.pos
+    data.pos = host_pos.to(device)            # the cloud itself is resident (it feeds the 3D branch too)
+    cold_ms, cold_t = call(data)
+    runs = [call(data) for _ in range(reps)]
+    steady_ms = float(np.median([r[0] for r in runs]))
+    phases = {k: float(np.median([r[1].get(k, 0.0) for r in runs])) for k in runs[0][1]}
+    # the same call with the cloud arriving as a host tensor (PCIe inside)
+    host = Data()
+    host.pos, host.mapping_index = host_pos, data.mapping_index
+    host.mvf_point_order = data.mvf_point_order
+    call(host)
+    host_ms = float(np.median([call(host)[0] for _ in range(reps)]))
+    return dict(
+        what="MapImages.__call__(data, images) wall clock, one C2 sample, exact splat visibility",
+        cold_ms=cold_ms, steady_ms=steady_ms, steady_ms_host_cloud=host_ms,
+        points_views_per_s=N * V / (steady_ms * 1e-3),
+        phases_ms={k: round(v, 4) for k, v in phases.items()},
+        cold_phases_ms={k: round(v, 4) for k, v in cold_t.items()},
+        note="t_sphere_sampling = local point order (KD-tree on the host when cold, cached on data when "
+             "steady); t_stage = ids / order / views to the device and permutation (no reference "
+             "counterpart); t_visibility = all kernels of the fused pass + read-back of the sizes, which "
+             "covers the reference's t_visibility, t_coord_pixels, t_unique_pixels, t_stack_pixels, "
+             "t_append; t_ImageMapping_init = wrap of the device CSR arrays")
 
 
 def main():
@@ -277,8 +607,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the nested short runs of the other workloads and the end-to-end timing")
+    ap.add_argument("--views", type=int, default=16, help="views of the c5 scene held by this rank")
     ap.add_argument("--lanes", type=int, default=3,
-                    help="streams that consecutive steps alternate between (1 = no overlap)")
+                    help="streams that consecutive samples alternate between (1 = no overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -294,157 +627,34 @@ def main():
 
     cfg = args.config
     if cfg == "c3":
-        run_qkv(args, rank, world, device, dist)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    C_feat = WORKLOADS[cfg]["channels"]
-    sc, plan = stage_sample(cfg, seed=2 + rank, device=device)
-    N, V = plan.N, plan.V
-    W, H = sc["img_size"]
-    gen = torch.Generator(device=device).manual_seed(rank)
-    labels = torch.randint(0, 19, (N,), device=device, generator=gen)
-    # pixel features for every possible mapping row, resident in HBM
-    plan.run()
-    cap = plan.out_cap
-    x_pix = torch.rand((cap, C_feat), device=device, generator=gen)
-    atomic_ptr = torch.arange(cap + 1, dtype=torch.int64, device=device)
-    lib = L.load()
+        line = run_qkv(args, rank, world, device, dist, cpu_leg=not args.no_cpu_baseline)
+    else:
+        line = run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=not args.no_cpu_baseline)
 
-    def pools(res):
-        pointers, img_ids, pixels, feats, view_seen = res
-        P = img_ids.shape[0]
-        # pixel -> view max, then view -> point max and mean, in one pass over x_pix
-        x_max, x_mean = segment_csr_two_level(x_pix[:P], atomic_ptr[:P + 1], pointers,
-                                              inner="max", outer=("max", "mean"))
-        return x_max, x_mean, P
-
-    # Consecutive samples are independent: steps alternate between two streams
-    # (each with its own plan: outputs and workspace), so that the
-    # latency-bound kernels of one step overlap with the other step's.  On each
-    # stream the mapping pass of the next step is enqueued before the sizes of
-    # the current one are waited for, so the device does not idle on the host
-    # round trip.
-    n_lanes = max(1, args.lanes)
-    plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
-    streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
-    # set-up: every lane allocates its outputs and workspace once
-    for p_, s_ in zip(plans, streams):
-        with torch.cuda.stream(s_):
-            p_.run()
-    torch.cuda.synchronize()
-
-    def run_steps(k):
-        """k full steps (mapping pass, size read-back, three pools each)."""
-        out = None
-        pending = [None] * n_lanes
-        for s in streams:
-            s.wait_stream(torch.cuda.current_stream(device))
-        for j in range(min(n_lanes, k)):
-            with torch.cuda.stream(streams[j]):
-                pending[j] = plans[j].run_async()
-        for j in range(k):
-            ln = j % n_lanes
-            with torch.cuda.stream(streams[ln]):
-                nxt = plans[ln].run_async() if j + n_lanes < k else None
-                out = pools(pending[ln].result())
-                pending[ln] = nxt
-        for s in streams:
-            torch.cuda.current_stream(device).wait_stream(s)
-        return out
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    out = run_steps(args.warmup) if args.warmup > 0 else None
-    if dist is not None and out is not None:
-        # untimed: the first collective of each kind sets up its RCCL channels
-        gather_pooled(torch.cat(out[:2], dim=1), labels)
-    barrier()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    if dist is not None:
-        # the path's only exchange: final gather of pooled features and labels
-        feats_all, labels_all, _ = gather_pooled(torch.cat(out[:2], dim=1), labels)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- per-kernel timing with HIP events on the launch stream (rank 0) ----
-    roofline = None
-    stages = {}
+    if rank == 0 and world == 1 and cfg == "c2" and not args.no_extras:
+        # short runs of the other workloads, so that one invocation records them all
+        line["end_to_end"] = end_to_end("c2", device)
+        others = {}
+        for name in ("c1", "c3", "c4", "c5"):
+            torch.cuda.empty_cache()
+            short = argparse.Namespace(**vars(args))
+            short.steps = 10 if name in ("c4", "c5") else max(10, min(args.steps, 30))
+            short.warmup = 3
+            if name == "c3":
+                r = run_qkv(short, 0, 1, device, None, cpu_leg=False)
+            else:
+                r = run_map_pool(name, short, 0, 1, device, None, cpu_leg=False)
+            rf = r["roofline"]
+            keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio",
+                    "kernel_ms", "stage_ms", "lds_atomic", "pipeline")
+            others[name] = dict(workload=r["config"]["workload"], value=r["value"], unit=r["unit"],
+                                ms_per_step=r["ms_per_step"], steps=r["steps"],
+                                points_per_gpu=r["config"].get("points_per_gpu"),
+                                views=r["config"].get("views"),
+                                mappings_per_sample=r["config"].get("mappings_per_sample"),
+                                roofline={k: rf[k] for k in keep if k in rf})
+        line["other_workloads"] = others
     if rank == 0:
-        lib.mvf_profile_enable(1)
-        ms = (C.c_float * 16)()
-        names = (C.c_char_p * 16)()
-        pool_ms = {"pools": 0.0}
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for _ in range(args.steps):
-            pointers, img_ids, pixels, feats, view_seen = plan.run()
-            n = lib.mvf_profile_read(ms, names, 16)
-            for i in range(n):
-                k = names[i].decode()
-                stages[k] = stages.get(k, 0.0) + ms[i]
-            P = img_ids.shape[0]
-            ev[0].record()
-            segment_csr_two_level(x_pix[:P], atomic_ptr[:P + 1], pointers, inner="max",
-                                  outer=("max", "mean"))
-            ev[1].record()
-            torch.cuda.synchronize()
-            pool_ms["pools"] += ev[0].elapsed_time(ev[1])
-        lib.mvf_profile_enable(0)
-        stages.update(pool_ms)
-        stages = {k: v / args.steps for k, v in stages.items()}          # ms per step
-        M = plan.last_counts["mappings"]
-        F = plan.F
-        Hc = H
-        B = algorithmic_bytes(N, V, W, Hc, M, F, C_feat)
-        charged = {"bin_count": B["projection"], "tile_zbuffer": B["zbuffer"],
-                   "csr_fill": B["emit"] + B["csr"], "pools": B["atomic_pool"] + B["view_pool"]}
-        charged = {k: v for k, v in charged.items() if k in stages}
-        dom = max(charged, key=lambda k: stages.get(k, 0.0))
-        ach = charged[dom] / (stages[dom] * 1e-3)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(cfg, {}).get(dom)
-        roofline = dict(
-            bound="hbm", kernel=dom, achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-            frac=ach / HBM_PEAK, traffic=traffic,
-            algorithmic_bytes_per_launch=charged[dom], kernel_ms=stages[dom],
-            pipeline=dict(
-                algorithmic_bytes_per_step=B["total"],
-                ms_per_step=elapsed / args.steps * 1e3,
-                achieved=B["total"] / (elapsed / args.steps) / 1e9,
-                frac=B["total"] / (elapsed / args.steps) / HBM_PEAK),
-            stage_ms={k: round(v, 4) for k, v in stages.items()})
-
-    if rank == 0:
-        line = {
-            "metric": "points*views mapped+fused/sec",
-            "value": world * N * V * args.steps / elapsed,
-            "unit": "points*views/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[cfg]["label"]
-                       + f", exact splat visibility + max atomic pool + max/mean view pools (C={C_feat}, pools fused in one pass)",
-                       "name": cfg, "points_per_gpu": N, "views": V, "image": [W, H],
-                       "mappings_per_sample": plan.last_counts["mappings"],
-                       "splat_tile_pairs": plan.last_counts["pairs"],
-                       "streams_per_gpu": n_lanes,
-                       "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
-            "roofline": roofline,
-        }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, C_feat)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

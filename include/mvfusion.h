@@ -225,6 +225,17 @@ int mvf_map_images_exact(
     float *features, int64_t out_capacity, int32_t *view_seen,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Profiling aid (no counterpart in the reference; bench.py's LDS-atomic
+ * roofline): counts what the z-buffer kernel of the mvf_map_images_exact call
+ * that last used `workspace` issued, from the tile bins it left there.  Pass
+ * the same sizes as to that call.  d_out (device, caller zeroes it):
+ * [0] += LDS atomic-minimum wave-instructions, [1] += lane-level atomics
+ * (pixels + cells written), [2] += (splat, tile) entries. */
+int mvf_profile_zbuffer_ops(
+    void *workspace, size_t workspace_bytes, int64_t n, int32_t V,
+    const mvf_vis_params *h_params, int64_t num_points, int64_t pair_capacity,
+    int64_t centre_slots, uint64_t *d_out, void *stream);
+
 /* ---------------------------------------------------------------------- *
  * MapImages._process with DepthBasedVisibility, all V views of one sample in
  * one launch set (core/data_transform/multimodal/image.py:192-428;

@@ -772,6 +772,74 @@ extern "C" int mvf_debug_zb_span(unsigned long long *out, int n)
 }
 #endif
 
+// Counts what tile_zbuffer_kernel issues for the bins of a call, without
+// touching any z-buffer: out[0] += LDS atomic wave-instructions (a loop step of
+// a wave counts once, whatever the number of active lanes), out[1] += lane-level
+// atomics (pixels and cells written), out[2] += (splat, tile) entries.  Mirrors
+// the dealing of entries to quarters and the rectangle sweep of raster_rect.
+template <unsigned PITCH_BYTES, bool SPLIT>
+__device__ __forceinline__ unsigned rect_trips(unsigned geom, unsigned shape, unsigned split, unsigned ly)
+{
+    const unsigned h = shape & 0xffu;
+    const unsigned lg = (shape >> 8) & 0xffu;
+    const unsigned xo = ly >> lg, yo = ly - (xo << lg);
+    if (yo >= h) return 0u;
+    const unsigned step = shape >> 16, end = geom >> 16;
+    unsigned a = (geom & 0xffffu) + xo * PITCH_BYTES + (yo << 3);
+    if (SPLIT) a += yo >= (split & 0xffu) ? split >> 8 : 0u;
+    return a < end ? (end - a + step - 1u) / step : 0u;
+}
+
+__device__ __forceinline__ unsigned wave_max(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(ZB_THREADS) void zbuffer_count_kernel(
+    const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
+    const unsigned *__restrict__ n_desc, i64 pair_capacity, u64 *__restrict__ out)
+{
+    const unsigned nd = *n_desc;
+    const int tid = threadIdx.x;
+    const unsigned ly = tid & 15, lane = tid & 63;
+    const int slot = ly * ZB_QUARTERS + ((ly & 1) ? ZB_QUARTERS - 1 - (tid >> 4) : (tid >> 4));
+    u64 instr = 0, lanes = 0, ents = 0;
+    for (unsigned k = blockIdx.x; k < nd; k += gridDim.x) {
+        const TileDesc d = descs[k];
+        i64 begin = d.begin, end = d.end;
+        if (end > pair_capacity) end = pair_capacity;
+        if (begin > end) begin = end;
+        const int x0 = d.origin & 0xffffu, y0 = d.origin >> 16;
+        for (i64 base = begin; base < end; base += ZB_THREADS) {
+            const i64 rem = end - base;
+            uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+            if (slot < rem) raw = *(const uint4 *)(entries + base + slot);
+            const StagedEntry mine = stage_entry(raw, x0, y0, slot < rem);
+            ents += wave_sum(slot < rem ? 1u : 0u);
+            const int maxj = rem >= ZB_THREADS ? 16 : (int)((rem + ZB_QUARTERS - 1) / ZB_QUARTERS);
+            for (int j = 0; j < maxj; ++j) {
+                const int from = (int)(lane & 48u) + j;              // lane j of the quarter's row
+                const unsigned t0 = rect_trips<ZC_PITCH_BYTES, false>(
+                    __shfl(mine.geom[0], from, 64), __shfl(mine.shape[0], from, 64), 0u, ly);
+                const unsigned t1 = rect_trips<ZB_PITCH_BYTES, true>(
+                    __shfl(mine.geom[1], from, 64), __shfl(mine.shape[1], from, 64),
+                    __shfl(mine.split, from, 64), ly);
+                instr += wave_max(t0) + wave_max(t1);
+                lanes += wave_sum(t0 + t1);
+            }
+        }
+    }
+    if (lane == 0) { atomicAdd(&out[0], instr); atomicAdd(&out[1], lanes); atomicAdd(&out[2], ents); }
+}
+
 // ------------------------------------------------------------------------- //
 // exact mode for the single-view API: stamp splat centres of seen points      //
 // ------------------------------------------------------------------------- //
@@ -1430,6 +1498,46 @@ extern "C" int mvf_mapping_features(
 
 // Number of slots of the centre-pixel table for a requested size: a power of
 // two, at least 1024.
+static inline i64 centre_table_slots(i64 requested);
+
+// The buffers mvf_map_images_exact cuts out of the caller's workspace.
+struct MapWorkspace {
+    i64 ncnt, seen_stride;
+    unsigned *tile_count, *tile_cur, *tile_off, *staged_count, *masks, *block_sums;
+    TileDesc *descs;
+    TileEntry *entries, *staged;
+    uint8_t *seen;
+    CentreTable table;
+    size_t clear_bytes, used;
+    bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
+               i64 pair_capacity, i64 centre_slots)
+    {
+        const i64 slots = centre_table_slots(centre_slots);
+        int slots_log = 0;
+        while ((1ll << slots_log) < slots) ++slots_log;
+        const int words = (V + 31) / 32;
+        Arena ar(workspace, workspace_bytes);
+        // counters are [tile][class]; behind them: number of non-empty tiles, z-buffer tickets
+        ncnt = tiles * NCLS;
+        tile_count = ar.take<unsigned>(ncnt + BIN_TAIL);
+        // the centre table sits right behind the counters: one memset clears both
+        table = CentreTable{ar.take<u64>((size_t)slots), (unsigned)(slots - 1), 64 - slots_log};
+        clear_bytes = ar.off;
+        tile_cur = ar.take<unsigned>(ncnt + BIN_TAIL);
+        tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
+        descs = ar.take<TileDesc>(tiles + 1);
+        entries = ar.take<TileEntry>(pair_capacity);
+        staged = ar.take<TileEntry>((size_t)V * cdiv(n, 256) * 256);
+        staged_count = ar.take<unsigned>((size_t)V * cdiv(n, 256));
+        seen_stride = seen_row_bytes(V);
+        seen = ar.take<uint8_t>((size_t)seen_stride * n);
+        masks = ar.take<unsigned>((size_t)words * num_points);
+        block_sums = ar.take<unsigned>(cdiv(num_points, 256));
+        used = ar.off;
+        return ar.ok();
+    }
+};
+
 static inline i64 centre_table_slots(i64 requested)
 {
     i64 t = 1024;
@@ -1441,19 +1549,34 @@ extern "C" size_t mvf_map_images_workspace_bytes(
     int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity,
     int64_t centre_slots)
 {
-    const size_t tiles = (size_t)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
-    const size_t nb = cdiv(num_points > 0 ? num_points : 1, 256);
-    const size_t words = (size_t)(V + 31) / 32;
-    size_t b = 0;
-    b += align_up((tiles * NCLS + BIN_TAIL) * sizeof(unsigned)) * 3;                    // count, cur, off
-    b += align_up((tiles + 1) * sizeof(TileDesc));
-    b += align_up((size_t)(pair_capacity > 0 ? pair_capacity : 1) * sizeof(TileEntry));
-    b += staged_bytes(n, V);
-    b += align_up((size_t)seen_row_bytes(V) * (size_t)(n > 0 ? n : 1));         // seen
-    b += align_up(words * (size_t)(num_points > 0 ? num_points : 1) * sizeof(unsigned));  // masks
-    b += align_up(nb * sizeof(unsigned));                                        // block sums
-    b += align_up((size_t)centre_table_slots(centre_slots) * sizeof(u64));
-    return b;
+    const i64 tiles = (i64)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    MapWorkspace ws;
+    ws.carve(nullptr, 0, n > 0 ? n : 1, V, tiles, num_points > 0 ? num_points : 1,
+             pair_capacity > 0 ? pair_capacity : 1, centre_slots);
+    return ws.used;
+}
+
+// LDS-atomic work of the z-buffer pass of the mvf_map_images_exact call that
+// last used `workspace` (same sizes): d_out[0..2] += wave-instructions, lane
+// atomics, entries (see zbuffer_count_kernel).
+extern "C" int mvf_profile_zbuffer_ops(
+    void *workspace, size_t workspace_bytes, int64_t n, int32_t V, const mvf_vis_params *h_params,
+    int64_t num_points, int64_t pair_capacity, int64_t centre_slots, uint64_t *d_out, void *stream)
+{
+    if (int rc = check_params(h_params, "profile_zbuffer_ops")) return rc;
+    MVF_REQUIRE(workspace && d_out && n >= 1 && V >= 1, "profile_zbuffer_ops: bad arguments");
+    int tiles_x, tiles_y, Hc;
+    tile_grid(*h_params, tiles_x, tiles_y, Hc);
+    const i64 tiles = (i64)tiles_x * tiles_y * V;
+    MapWorkspace ws;
+    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, centre_slots)) {
+        set_error("profile_zbuffer_ops: workspace too small");
+        return MVF_E_WORKSPACE;
+    }
+    hipLaunchKernelGGL(zbuffer_count_kernel, dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, (hipStream_t)stream,
+                       ws.entries, ws.descs, ws.tile_count + ws.ncnt, (i64)pair_capacity, (u64 *)d_out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
 }
 
 extern "C" int mvf_map_images_exact(
@@ -1486,30 +1609,19 @@ extern "C" int mvf_map_images_exact(
     const int tiles_per_view = tiles_x * tiles_y;
     const i64 tiles = (i64)tiles_per_view * V;
     const i64 nb = cdiv(num_points, 256);
-    const int words = (V + 31) / 32;
-    const i64 slots = centre_table_slots(centre_slots);
-    int slots_log = 0;
-    while ((1ll << slots_log) < slots) ++slots_log;
-
-    Arena ar(workspace, workspace_bytes);
-    // counters are [tile][class]; two extra words behind tile_count: number of
-    // non-empty tiles, z-buffer ticket counter
-    const i64 ncnt = tiles * NCLS;
-    unsigned *tile_count = ar.take<unsigned>(ncnt + BIN_TAIL);
-    // the centre table sits right behind the counters: one memset clears both
-    CentreTable table{ar.take<u64>((size_t)slots), (unsigned)(slots - 1), 64 - slots_log};
-    const size_t clear_bytes = ar.off;
-    unsigned *tile_cur = ar.take<unsigned>(ncnt + BIN_TAIL);
-    unsigned *tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
-    TileDesc *descs = ar.take<TileDesc>(tiles + 1);
-    TileEntry *entries = ar.take<TileEntry>(pair_capacity);
-    TileEntry *staged = ar.take<TileEntry>((size_t)V * cdiv(n, 256) * 256);
-    unsigned *staged_count = ar.take<unsigned>((size_t)V * cdiv(n, 256));
-    const i64 seen_stride = seen_row_bytes(V);
-    uint8_t *seen = ar.take<uint8_t>((size_t)seen_stride * n);
-    unsigned *masks = ar.take<unsigned>((size_t)words * num_points);
-    unsigned *block_sums = ar.take<unsigned>(nb);
-    if (!ar.ok()) { set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
+    MapWorkspace ws;
+    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, centre_slots)) {
+        set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ws.used);
+        return MVF_E_WORKSPACE;
+    }
+    const i64 ncnt = ws.ncnt, seen_stride = ws.seen_stride;
+    unsigned *tile_count = ws.tile_count, *tile_cur = ws.tile_cur, *tile_off = ws.tile_off;
+    TileDesc *descs = ws.descs;
+    TileEntry *entries = ws.entries, *staged = ws.staged;
+    unsigned *staged_count = ws.staged_count, *masks = ws.masks, *block_sums = ws.block_sums;
+    uint8_t *seen = ws.seen;
+    const CentreTable table = ws.table;
+    const size_t clear_bytes = ws.clear_bytes;
 
     prof_begin(st);
     MVF_HIP(hipMemsetAsync(tile_count, 0, clear_bytes, st));

@@ -22,6 +22,7 @@ needs no host work; a precomputed permutation may be supplied as
 ``data.mvf_point_order``.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -84,17 +85,30 @@ def kdtree_order(pos, cylinder):
     return torch.from_numpy(np.asarray(tree.idx_array).astype(np.int64))
 
 
+_VIEW_DTYPE = np.dtype({
+    'names': ['img_xyz', 'fx', 'fy', 'cx', 'cy', 'cam_to_world', 'centre', 'crop_off_x', 'crop_off_y'],
+    'formats': [('f4', 3), 'f4', 'f4', 'f4', 'f4', ('f4', 16), ('f8', 3), 'i4', 'i4'],
+    'offsets': [0, 12, 16, 20, 24, 28, 96, 120, 124], 'itemsize': 128})
+
+
 def pack_views(images, camera):
-    """[V] mvf_view structs as a host uint8 tensor."""
+    """[V] mvf_view structs of pinhole views as a host uint8 tensor (the layout
+    of ``_lib.MvfView``; what ``visibility.make_view`` fills for one view)."""
+    assert camera in ('kitti360_perspective', 'scannet')
     V = images.num_views
-    arr = (L.MvfView * V)()
-    K = images.intrinsic_pinhole.float()
-    for v in range(V):
-        arr[v] = visibility_module.make_view(
-            images.pos[v].float(), K[v], images.extrinsic[v].float(), camera,
-            centre=images.pos[v].double(), crop_offsets=images.crop_offsets[v].tolist())
-    buf = np.frombuffer(arr, dtype=np.uint8).copy()
-    return torch.from_numpy(buf)
+    arr = np.zeros(V, dtype=_VIEW_DTYPE)
+    pos = np.asarray(images.pos.detach().cpu())
+    arr['img_xyz'] = pos.astype(np.float32)
+    arr['centre'] = pos.astype(np.float64)
+    for name, key in (('fx', 'fx'), ('fy', 'fy'), ('cx', 'mx'), ('cy', 'my')):
+        arr[name] = np.asarray(torch.as_tensor(getattr(images, key)).detach().cpu().float())
+    E = np.ascontiguousarray(np.asarray(images.extrinsic.detach().cpu().float()))
+    if camera == 'scannet':
+        E = np.linalg.inv(E)             # the reference inverts the float32 matrix (visibility.py:233)
+    arr['cam_to_world'] = E.reshape(V, 16).astype(np.float32)
+    off = np.asarray(images.crop_offsets.detach().cpu()).astype(np.int32)
+    arr['crop_off_x'], arr['crop_off_y'] = off[:, 0], off[:, 1]
+    return torch.from_numpy(arr.view(np.uint8).reshape(V * 128).copy())
 
 
 def _stack_depth_maps(images, device):
@@ -305,6 +319,10 @@ class MapImages(ImageTransform):
         assert self.point_order in ('kdtree', 'index')
         # streams a list of samples is spread over (fused path only)
         self.lanes = int(kwargs.pop('lanes', 3))
+        # where the mappings go: None = the device of the images (what the
+        # reference returns); a HIP device keeps them where they were computed
+        # (the small per-view tensors of the images stay where they are)
+        self.output_device = kwargs.pop('output_device', None)
         self.kwargs = kwargs
         self._pair_cap = None
         self._out_cap = None
@@ -313,12 +331,20 @@ class MapImages(ImageTransform):
 
     # ------------------------------------------------------------------ #
     def _order(self, data):
+        """Local point order of the sample; the KD-tree order is kept on
+        ``data`` for the next call, as the reference keeps the tree itself
+        (transforms.py:325-329,379-383)."""
         order = getattr(data, ORDER_KEY, None)
         if order is not None:
             return order
         if self.point_order == 'index':
             return None
-        return kdtree_order(data.pos, self.cylinder)
+        order = kdtree_order(data.pos, self.cylinder)
+        try:
+            setattr(data, ORDER_KEY, order)
+        except Exception:
+            pass
+        return order
 
     def _fusable(self, images, visi_model):
         """Can all views of these images go through one launch set?  Exact splat
@@ -420,6 +446,8 @@ class MapImages(ImageTransform):
         in_device = images.device
         device = L.require_device(data.pos)
         visi_model = self._settle(data, images)
+        self.timings = dict(t_sphere_sampling=0.0, t_stage=0.0, t_visibility=0.0,
+                            t_ImageMapping_init=0.0)
 
         mappings = seen = None
         if self._fusable(images, visi_model):
@@ -427,39 +455,94 @@ class MapImages(ImageTransform):
             if res is not None:
                 mappings, seen = res
         if mappings is None:
+            t0 = time.perf_counter()
             mappings, seen = self._process_per_view(data, images, visi_model, device)
+            self.timings['t_visibility'] = (time.perf_counter() - t0) * 1e3
 
+        t0 = time.perf_counter()
         if seen.shape[0] != images.num_views:
             images = images[seen.to(in_device)]
-        images.mappings = mappings.to(in_device)
+        out_device = in_device if self.output_device is None else torch.device(self.output_device)
+        images.mappings = mappings.to(out_device)
         images.visibility = visi_model
+        self.timings['t_ImageMapping_init'] += (time.perf_counter() - t0) * 1e3
         return data, images
 
     # ------------------------------------------------------------------ #
+    def _stage_points(self, data, order, device):
+        """The per-point inputs of the fused path on the device: points (and
+        attributes) permuted into the local order, their mapping ids, the
+        position of every id.  Kept on ``data`` (next to the point order) for
+        the next call on the same, unmodified tensors -- a sample is usually
+        mapped once per image setting.  None when mapping ids repeat or are
+        negative."""
+        N = data.pos.shape[0]
+        ids = getattr(data, self.key)
+        names = ('linearity', 'planarity', 'scattering', 'norm')
+        src = [data.pos, ids, order] + [getattr(data, k, None) for k in names]
+        key = (str(device),) + tuple(
+            None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in src)
+        cached = getattr(data, '_mvf_staged', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if not ids.is_cuda:
+            # host ids: range and distinctness are settled here, without a device round trip
+            ids_h = np.asarray(ids.detach(), dtype=np.int64)
+            lo, hi = (int(ids_h.min()), int(ids_h.max())) if N else (0, -1)
+            num_points = hi + 1
+            if lo < 0:
+                return None
+            inv_h = np.full(num_points, -1, dtype=np.int64)
+            src_h = np.arange(N, dtype=np.int64)
+            if order is not None:            # position of every point in the local order
+                src_h = np.empty(N, dtype=np.int64)
+                src_h[np.asarray(order.cpu(), dtype=np.int64)] = np.arange(N, dtype=np.int64)
+            inv_h[ids_h] = src_h
+            if int((inv_h >= 0).sum()) != N:
+                return None      # repeated mapping ids: several pixels per (point, view)
+            inv = torch.from_numpy(inv_h).to(device, non_blocking=True)
+            ids = ids.to(device=device, dtype=torch.int64, non_blocking=True)
+        else:
+            inv = None
+            ids = ids.to(device=device, dtype=torch.int64)
+        pos = data.pos.to(device=device, dtype=torch.float32, non_blocking=True)
+        attrs = [getattr(data, k, None) for k in names]
+        attrs = [a.to(device=device, dtype=torch.float32, non_blocking=True) if a is not None else None
+                 for a in attrs]
+        if order is not None:
+            order = order.to(device, non_blocking=True)
+            pos, ids = pos[order], ids[order]
+            attrs = [a[order] if a is not None else None for a in attrs]
+        if inv is None:
+            num_points = int(ids.max().item()) + 1
+            inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
+            inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
+            if int((inv >= 0).sum().item()) != N or int(ids.min().item()) < 0:
+                return None      # repeated mapping ids: several pixels per (point, view)
+        staged = (pos.contiguous(), ids.contiguous(), inv,
+                  [a.contiguous() if a is not None else None for a in attrs], num_points)
+        try:
+            data._mvf_staged = (key, staged)
+        except Exception:
+            pass
+        return staged
+
     def prepare_fused(self, data, images, visi_model, device):
         """Stage one sample on the device for the fused path: points permuted
         into the sampler's order, mapping ids and their inverse, packed views.
         Returns a FusedMapPlan, or None when mapping ids repeat."""
         N = data.pos.shape[0]
         depth = self.method == 'DepthBasedVisibility'
+        t0 = time.perf_counter()
         # the depth test has no ties: any point order gives the same mappings
         order = None if depth else self._order(data)
-        ids = getattr(data, self.key).to(device=device, dtype=torch.int64)
-        pos = data.pos.to(device=device, dtype=torch.float32)
-        attrs = [getattr(data, k, None) for k in ('linearity', 'planarity', 'scattering', 'norm')]
-        attrs = [a.to(device=device, dtype=torch.float32) if a is not None else None for a in attrs]
-        if order is not None:
-            order = order.to(device)
-            pos, ids = pos[order], ids[order]
-            attrs = [a[order] if a is not None else None for a in attrs]
-        num_points = int(ids.max().item()) + 1
-        inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
-        inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
-        if int((inv >= 0).sum().item()) != N or int(ids.min().item()) < 0:
-            return None      # repeated mapping ids: several pixels per (point, view)
+        self.timings['t_sphere_sampling'] = (time.perf_counter() - t0) * 1e3
+        staged = self._stage_points(data, order, device)
+        if staged is None:
+            return None
+        pos, ids, inv, attrs, num_points = staged
         return FusedMapPlan(
-            pos.contiguous(), ids.contiguous(), inv,
-            [a.contiguous() if a is not None else None for a in attrs],
+            pos, ids, inv, attrs,
             pack_views(images, visi_model.camera).to(device),
             images.mask.to(device=device, dtype=torch.uint8).contiguous()
             if images.mask is not None else None,
@@ -470,16 +553,26 @@ class MapImages(ImageTransform):
             depth_maps=_stack_depth_maps(images, device) if depth else None)
 
     def _process_fused(self, data, images, visi_model, device):
+        """The phases are host wall clock (ms): work enqueued by one phase may
+        run during the next; ``t_visibility`` ends with the read-back of the
+        sizes, which waits for everything before it."""
+        t0 = time.perf_counter()
         plan = self.prepare_fused(data, images, visi_model, device)
         if plan is None:
             return None
+        t1 = time.perf_counter()
         pointers, img_ids, pixels, feats, view_seen = plan.run()
+        t2 = time.perf_counter()
         self._pair_cap, self._out_cap = plan.pair_cap, plan.out_cap
         self._centre_slots = plan.centre_slots
         if img_ids.shape[0] == 0:
             raise ValueError(_NO_MAPPING_MSG)
         mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)
-        return mappings, torch.where(view_seen > 0)[0]
+        seen = torch.where(view_seen > 0)[0]
+        self.timings['t_stage'] = (t1 - t0) * 1e3 - self.timings['t_sphere_sampling']
+        self.timings['t_visibility'] = (t2 - t1) * 1e3
+        self.timings['t_ImageMapping_init'] = (time.perf_counter() - t2) * 1e3
+        return mappings, seen
 
     # ------------------------------------------------------------------ #
     def _process_per_view(self, data, images, visi_model, device):
