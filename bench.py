@@ -82,7 +82,7 @@ def host_sample(scene, seed, n_views=None):
     return sc, data, images
 
 
-def stage_sample(scene, seed, device, depth=False, n_views=None):
+def stage_sample(scene, seed, device, depth=False, n_views=None, exact=True):
     """Build one synthetic sample on the host and stage it in HBM."""
     sc, data, images = host_sample(scene, seed, n_views)
     if depth:
@@ -97,19 +97,21 @@ def stage_sample(scene, seed, device, depth=False, n_views=None):
         model = visibility_module.DepthBasedVisibility(img_size=images.proj_size, depth_threshold=0.05, **vis)
     else:
         data.mvf_point_order = kdtree_order(data.pos, True)
-        t = MapImages(method="SplattingVisibility", cylinder=True, **VIS)
-        model = visibility_module.SplattingVisibility(img_size=images.proj_size, **VIS)
+        vis = dict(VIS, exact=bool(exact))
+        t = MapImages(method="SplattingVisibility", cylinder=True, **vis)
+        model = visibility_module.SplattingVisibility(img_size=images.proj_size, **vis)
     plan = t.prepare_fused(data, images, model, device)
     return sc, plan
 
 
-def algorithmic_bytes(N, V, W, Hc, M, F, C, depth=False, m_fov=0):
+def algorithmic_bytes(N, V, W, Hc, M, F, C, depth=False, m_fov=0, Vw=None):
     """Closed-form byte model: xyz read once per view, one write + one read of
     an 8-byte z-buffer cell per pixel (splat visibility) or one 4-byte depth
     gather per in-view point (depth-map visibility), the emitted mappings, the
     output CSR, and each pool reading its input once and writing its output
     once."""
-    Vw = P = M
+    P = M                          # mapped pixels; Vw view-level rows (one pixel each unless given)
+    Vw = M if Vw is None else Vw
     b = {}
     b["projection"] = V * 12 * N
     b["zbuffer"] = 4 * m_fov if depth else V * 16 * W * Hc
@@ -350,8 +352,9 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     depth = cfg == "c5"
     n_samples = wl.get("samples", 1)
     n_views = args.views if depth else None
+    exact = bool(getattr(args, "exact", 1))
     staged = [stage_sample(wl["scene"], seed=2 + rank * n_samples + k, device=device, depth=depth,
-                           n_views=n_views) for k in range(n_samples)]
+                           n_views=n_views, exact=exact) for k in range(n_samples)]
     sc, plan = staged[0]
     N, V = plan.N, plan.V
     W, H = sc["img_size"]
@@ -361,16 +364,24 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     # pixel features for every possible mapping row, resident in HBM
     for _, p in staged:
         p.run()
-    cap = sum(p.out_cap for _, p in staged)
+    splat = plan.splat                  # plain splat visibility: several pixels per (point, view)
+    cap = sum(p.pix_cap if splat else p.out_cap for _, p in staged)
     x_pix = torch.rand((cap, C_feat), device=device, generator=gen)
-    atomic_ptr = torch.arange(cap + 1, dtype=torch.int64, device=device)
+    atomic_ptr = None if splat else torch.arange(cap + 1, dtype=torch.int64, device=device)
     lib = L.load()
     tm = Timer(dist, device)
 
-    def pools(pointers, n_rows):
+    def pools(pointers, n_rows, view_ptr=None, n_pix=None):
         # pixel -> view max, then view -> point max and mean, in one pass over x_pix
-        return segment_csr_two_level(x_pix[:n_rows], atomic_ptr[:n_rows + 1], pointers,
+        if view_ptr is None:
+            view_ptr, n_pix = atomic_ptr[:n_rows + 1], n_rows
+        return segment_csr_two_level(x_pix[:n_pix], view_ptr, pointers,
                                      inner="max", outer=("max", "mean"))
+
+    def pools_of(res):
+        if splat:
+            return pools(res[0], res[1].shape[0], res[5], res[2].shape[0])
+        return pools(res[0], res[1].shape[0])
 
     # Consecutive samples are independent: they alternate between streams (each
     # with its own plan: outputs and workspace), so that the latency-bound
@@ -406,8 +417,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             ln = j % n_lanes
             with torch.cuda.stream(streams[ln]):
                 nxt = plans[ln].run_async() if j + n_lanes < k else None
-                pointers, img_ids, _, _, _ = pending[ln].result()
-                out = pools(pointers, img_ids.shape[0])
+                out = pools_of(pending[ln].result())
                 pending[ln] = nxt
         for s in streams:
             cur.wait_stream(s)
@@ -438,12 +448,16 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             maps = []
             for p, pd in zip(plans, pend):
                 with torch.cuda.stream(streams[p.lane]):
-                    pointers, img_ids, pixels, feats, _ = pd.result()
-                maps.append(ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats))
+                    res = pd.result()
+                maps.append(ImageMapping.from_csr_arrays(res[0], res[1], res[2], res[3], *res[5:]))
             # result() has waited for every pass of this step: the pools may read them
             with torch.cuda.stream(pool_stream):
                 batch = ImageMappingBatch.from_csr_list(maps)
-                out = pools(batch.view_csr_indexing, batch.images.shape[0])
+                if splat:
+                    out = pools(batch.view_csr_indexing, batch.images.shape[0],
+                                batch.atomic_csr_indexing, batch.pixels.shape[0])
+                else:
+                    out = pools(batch.view_csr_indexing, batch.images.shape[0])
             pend = nxt
         for s in streams:
             cur.wait_stream(s)
@@ -473,23 +487,23 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     n_prof = min(args.steps, 50)
     for _ in range(n_prof):
-        pointers, img_ids, pixels, feats, view_seen = plan.run()
+        res = plan.run()
         n = lib.mvf_profile_read(ms, names, 16)
         for i in range(n):
             k = names[i].decode()
             stages[k] = stages.get(k, 0.0) + ms[i]
-        P = img_ids.shape[0]
         ev[0].record()
-        pools(pointers, P)
+        pools_of(res)
         ev[1].record()
         torch.cuda.synchronize()
         stages["pools"] = stages.get("pools", 0.0) + ev[0].elapsed_time(ev[1])
     lib.mvf_profile_enable(0)
     stages = {k: v / n_prof for k, v in stages.items()}          # ms per sample
-    M = plan.last_counts["mappings"]
+    M = plan.last_counts["pixels"] if splat else plan.last_counts["mappings"]
     # depth-map visibility: one depth gather per in-view (point, view) pair; the
     # pairs that pass the test are a lower bound of those that reach it
-    B = algorithmic_bytes(N, V, W, H, M, plan.F, C_feat, depth=depth, m_fov=M)
+    B = algorithmic_bytes(N, V, W, H, M, plan.F, C_feat, depth=depth, m_fov=M,
+                          Vw=plan.last_counts["mappings"])
     if depth:
         charged = {"point_mask": B["projection"] + B["zbuffer"], "csr_fill": B["emit"] + B["csr"],
                    "pools": B["atomic_pool"] + B["view_pool"]}
@@ -540,17 +554,19 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": label
-                   + (", depth-map visibility" if depth else ", exact splat visibility")
+                   + (", depth-map visibility" if depth else
+                      ", exact splat visibility" if exact else ", plain splat visibility (exact=False)")
                    + f" + max atomic pool + max/mean view pools (C={C_feat}, pools fused in one pass)",
                    "name": cfg, "points_per_gpu": N_all, "views": V, "image": [W, H],
                    "samples_per_step": n_samples,
                    "mappings_per_sample": plan.last_counts["mappings"],
+                   "pixels_per_sample": plan.last_counts["pixels"] if splat else plan.last_counts["mappings"],
                    "splat_tile_pairs": plan.last_counts["pairs"],
                    "streams_per_gpu": n_lanes,
                    "parallelism": f"sample-sharded x{world}, final RCCL all-gather"},
         "roofline": roofline,
     }
-    if cpu_leg and not depth and n_samples == 1:
+    if cpu_leg and not depth and n_samples == 1 and exact:
         line["cpu_baseline"] = cpu_baseline(wl["scene"], C_feat)
     return line
 
@@ -610,6 +626,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the nested short runs of the other workloads and the end-to-end timing")
     ap.add_argument("--views", type=int, default=16, help="views of the c5 scene held by this rank")
+    ap.add_argument("--exact", type=int, default=1,
+                    help="0: plain splat visibility (every pixel a point wins is a mapping) for c1 / c2 / c4")
     ap.add_argument("--lanes", type=int, default=3,
                     help="streams that consecutive samples alternate between (1 = no overlap)")
     args = ap.parse_args()
@@ -631,7 +649,7 @@ def main():
     else:
         line = run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=not args.no_cpu_baseline)
 
-    if rank == 0 and world == 1 and cfg == "c2" and not args.no_extras:
+    if rank == 0 and world == 1 and cfg == "c2" and args.exact and not args.no_extras:
         # short runs of the other workloads, so that one invocation records them all
         line["end_to_end"] = end_to_end("c2", device)
         others = {}

@@ -203,7 +203,7 @@ int mvf_mapping_features(
  * features ([Vw][F]) with room for out_capacity views; view_seen [V] flags.
  * Since every (point, view) maps to one pixel the nested pixel pointers are
  * arange(Vw+1) and are not written.
- * counters[0] <- Vw, [1] <- (splat, tile) pairs needed, [2] <- overflow flags
+ * counters (8 words) [0] <- Vw, [1] <- (splat, tile) pairs needed, [2] <- overflow flags
  * (bit 0: pair_capacity or out_capacity exceeded, bit 1: centre table full;
  * outputs are then incomplete: call again with larger sizes),
  * [3] <- number of views with at least one mapping.
@@ -223,6 +223,34 @@ int mvf_map_images_exact(
     int32_t crop_w, int32_t crop_h, int64_t centre_slots,
     int64_t pair_capacity, int64_t *pointers, int64_t *images, int16_t *pixels,
     float *features, int64_t out_capacity, int32_t *view_seen,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
+ * MapImages._process with SplattingVisibility(exact=False), all V views of one
+ * sample in one launch set (core/data_transform/multimodal/image.py:192-428;
+ * visibility_from_splatting_cpu without the exact step,
+ * core/multimodal/visibility.py:1073-1162,1190-1195; ImageMapping.from_dense,
+ * core/multimodal/image.py:1738-1805): every pixel a point wins in the z-buffer
+ * is a mapping.  Arguments as for mvf_map_images_exact; proj_upscale and
+ * downscale must be 1 (other factors merge pixels and go view by view).
+ * Outputs: pointers [num_points+1]; images [Vw] and view_pointers [Vw+1] with
+ * room for out_capacity views; pixels (int16 [P][2], ascending (x, y) inside a
+ * view: the reference's order inside a view is unspecified) with room for
+ * pix_capacity; features [Vw][F] = mean over the view's pixels.
+ * counters (8 words): [0] <- Vw, [1] <- (splat, tile) pairs needed,
+ * [2] <- overflow flags (bit 0: pair_capacity or out_capacity, bit 2:
+ * pix_capacity), [3] <- views with at least one mapping, [4] <- P.
+ * ---------------------------------------------------------------------- */
+size_t mvf_map_images_splat_workspace_bytes(
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity);
+int mvf_map_images_splat(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points,
+    const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
+    int32_t cylinder, const uint8_t *mask, const float *linearity,
+    const float *planarity, const float *scattering, const float *normals,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers,
+    int64_t *images, int64_t *view_pointers, int16_t *pixels, float *features,
+    int64_t out_capacity, int64_t pix_capacity, int32_t *view_seen,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Profiling aid (no counterpart in the reference; bench.py's LDS-atomic
@@ -245,8 +273,8 @@ int mvf_profile_zbuffer_ops(
  * the depth test has no ties); depth_maps: [V][W][H] float32, decoded as
  * read_s3dis_depth_map returns them (visibility.py:1328-1358);
  * h_params->depth_threshold is the tolerance.  Both fused entry points take at
- * most 480 views per call.  counters[0] <- Vw, [2] <- 1 if out_capacity was
- * exceeded, [3] <- number of views with at least one mapping.
+ * most 480 views per call.  counters (8 words): [0] <- Vw, [2] <- 1 if
+ * out_capacity was exceeded, [3] <- number of views with at least one mapping.
  * ---------------------------------------------------------------------- */
 size_t mvf_map_images_depth_workspace_bytes(int64_t num_points, int32_t V);
 int mvf_map_images_depth(
@@ -334,6 +362,21 @@ int mvf_gather_pool(
 int mvf_gather_features(
     const float *x, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *batch,
     const int16_t *pixels, int64_t rows, float *out, void *stream);
+
+/* Gradient of X[mappings.feature_map_indexing] with respect to X (what autograd
+ * attaches to the indexing of core/multimodal/image.py:1295): grad_x [B][C][H][W]
+ * (the caller zeroes it) += grad_out [rows][C] at the rows' pixels.  Rows that
+ * share a pixel are added atomically (order dependent in the last bits). */
+int mvf_gather_features_backward(
+    const float *grad_out, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *batch,
+    const int16_t *pixels, int64_t rows, float *grad_x, void *stream);
+
+/* Gradient of sparse_interpolation (core/multimodal/image.py:105-170) with
+ * respect to the feature maps: grad_x (zeroed by the caller) += the four
+ * bilinear weights of every query times its gradient row. */
+int mvf_sparse_interpolation_backward(
+    const float *grad_out, int32_t B, int32_t C, int32_t H, int32_t W, const float *coords,
+    const int64_t *batch, int64_t rows, int32_t padding_mode, float *grad_x, void *stream);
 
 /* sparse_interpolation (core/multimodal/image.py:105-170): bilinear sampling
  * of x [B][C][H][W] at coords [rows][2] = (row, column) in [0, 1] on the map
@@ -454,10 +497,12 @@ int mvf_csr_row_segments(const int64_t *ptr, int64_t nseg, int32_t *row2seg, voi
 
 /* HeuristicBimodalCSRPool.forward (pooling.py:129-152): out[s] = x_mod[row of
  * the segment's largest (pick_max) or smallest value of feat], zeros for an
- * empty segment; feat is one column of the mapping features, stride ldf. */
+ * empty segment; feat is one column of the mapping features, stride ldf.
+ * picked (may be NULL): [nseg] the chosen row of every segment, -1 for an empty
+ * one (the rows the gradient of x_mod goes to). */
 int mvf_segment_pick(
     const float *x_mod, int32_t C, const float *feat, int32_t ldf, const int64_t *ptr,
-    int64_t nseg, int32_t pick_max, float *out, void *stream);
+    int64_t nseg, int32_t pick_max, float *out, int64_t *picked, void *stream);
 
 /* ---------------------------------------------------------------------- *
  * NeighborhoodBasedMappingFeatures

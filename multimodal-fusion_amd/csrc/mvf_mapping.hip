@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     const int v = blockIdx.y;
     // the first block also clears the caller's small output arrays
     if (blockIdx.x == 0 && v == 0) {
-        if (zero_counters && tid < 4) zero_counters[tid] = 0;
+        if (zero_counters && tid < 8) zero_counters[tid] = 0;
         if (zero_view_seen) for (int k = tid; k < V; k += 256) zero_view_seen[k] = 0;
     }
     const bool live = i < src.count();
@@ -519,9 +519,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(
 // b + 2G ... (G = grid size) and fetches the next tile's descriptor and first
 // entries while the current tile is still being rasterised, so the per-tile
 // latency chain (descriptor -> entries) is off the critical path.
-// WRITE_IDMAP: store winner + 1 of every pixel of a non-empty tile to
-// idmap[v][x][y] (the caller pre-zeroes idmap).  Otherwise mark
-// seen[winner][v] = 1 (exact mode; seen_stride bytes per point).
+// MODE 0: mark seen[winner][v] = 1 (seen_stride bytes per point).
+// MODE 1: store winner + 1 of every won pixel to idmap[v][x][y] (the caller
+// pre-zeroes idmap).  MODE 2: both, and the empty pixels of a non-empty tile
+// are stored as 0, so that the tiles a splat touches are complete without any
+// clearing of idmap.
 constexpr int ZB_THREADS = TILE_X * TILE_Y / 8;  // one 8-pixel column piece per thread
 #ifndef MVF_ZB_WG_PER_CU
 #define MVF_ZB_WG_PER_CU (MVF_TILE_Y_LOG == 6 ? 3 : 6)
@@ -547,7 +549,7 @@ __device__ unsigned g_zb_tile[16384 * 2];
 __device__ unsigned g_zb_log[1024 * 16 * 3];            // per workgroup and tile: list position, end time, entries             // per list position: duration (10 ns), entries   // per workgroup: first / last wall clock, tiles done
 #endif
 
-template <bool WRITE_IDMAP>
+template <int MODE>
 #ifdef MVF_ZB_SPAN
 __attribute__((amdgpu_num_sgpr(76)))
 #endif
@@ -681,15 +683,16 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
                 const u64 c = k < 4 ? c0 : c1;
                 id[k] = (unsigned)(key[k] < c ? key[k] : c);
             }
-            if (WRITE_IDMAP) {
+            if (MODE != 0) {
                 const int gx = x0 + col, gy = y0 + rb * 8;
                 if (gx < W) {
                     unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
 #pragma unroll
                     for (int k = 0; k < 8; ++k)
-                        if (id[k] != 0xffffffffu && gy + k < Hc) im[k] = id[k] + 1u;
+                        if ((MODE == 2 || id[k] != 0xffffffffu) && gy + k < Hc) im[k] = id[k] + 1u;
                 }
-            } else {
+            }
+            if (MODE != 1) {
                 // A winner is marked where neither the pixel above (inside the
                 // piece) nor the pixel to the left (the first lane of a row goes
                 // without) shows it: its top-left visible pixel always qualifies.
@@ -1188,6 +1191,191 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
     }
 }
 
+// ------------------------------------------------------------------------- //
+// fused MapImages (plain splat visibility, exact = False): every pixel a      //
+// point wins is a mapping (visibility.py:1190-1195)                           //
+// ------------------------------------------------------------------------- //
+// After the tile pass idmap[v][x][y] holds winner + 1 of every pixel of the
+// tiles that received a splat, and seen[i][v] the points that won a pixel.  A
+// point's pixels in a view lie inside its splat box, so a row of 16 lanes
+// walks the box of every seen (point, view) pair, column by column, and picks
+// the pixels the id map attributes to the point: once to count them, and, after
+// the CSR offsets are known, again to store them -- in ascending (x, y) order,
+// with no sort.  The boxes come from the records the binning count pass staged
+// (one block per 256 points and view), so nothing is projected again.
+// FILL = false: cnt[i][v] <- pixels of the pair inside the crop.
+// FILL = true: pixels[poff[i][v] ...] <- those pixels.
+template <bool FILL>
+__global__ __launch_bounds__(256) void ne_scan_kernel(
+    const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
+    const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ idmap,
+    const mvf_view *__restrict__ views, int W, int Hc, int crop_top, int crop_w, int crop_h, int V,
+    unsigned *__restrict__ cnt, const i64 *__restrict__ poff, int16_t *__restrict__ pixels,
+    i64 pix_capacity)
+{
+    __shared__ TileEntry list[256];
+    const int tid = threadIdx.x, v = blockIdx.y;
+    const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
+    const unsigned n = staged_count[blk];
+    if (n == 0) return;
+    TileEntry e;
+    e.key = 0; e.xa = e.xb = e.ya = e.yb = 0;
+    bool have = false;
+    if ((unsigned)tid < n) {
+        e = staged[blk * 256 + tid];
+        have = seen[(size_t)(unsigned)e.key * seen_stride + v] != 0;
+    }
+    unsigned total;
+    const unsigned rank = block_rank_flag(have, total);
+    if (have) list[rank] = e;
+    __syncthreads();
+    const unsigned quarter = tid >> 4, ly = tid & 15, sh = 16u * ((tid >> 4) & 3u);
+    const int off_x = views[v].crop_off_x, off_y = views[v].crop_off_y;
+    for (unsigned r = quarter; r < total; r += 16u) {
+        const TileEntry b = list[r];
+        const unsigned id = (unsigned)b.key;
+        const i64 base = FILL ? poff[(size_t)id * V + v] : 0;
+        unsigned count = 0;
+        for (int x = b.xa; x < (int)b.xb; ++x) {
+            const int px = x - off_x;
+            if (px < 0 || px >= crop_w) continue;
+            const unsigned *col = idmap + ((size_t)v * W + x) * Hc;
+            for (int y0 = b.ya; y0 < (int)b.yb; y0 += 16) {
+                const int y = y0 + (int)ly, py = y + crop_top - off_y;
+                const bool ok = y < (int)b.yb && col[y] == id + 1u && py >= 0 && py < crop_h;
+                const unsigned m = (unsigned)(__ballot(ok) >> sh) & 0xffffu;      // this row of 16 lanes
+                if (FILL && ok) {
+                    const i64 pos = base + count + __popc(m & ((1u << ly) - 1u));
+                    if (pos < pix_capacity) { pixels[2 * pos] = (int16_t)px; pixels[2 * pos + 1] = (int16_t)py; }
+                }
+                count += __popc(m);
+            }
+        }
+        if (!FILL && ly == 0) cnt[(size_t)id * V + v] = count;
+    }
+}
+
+// One thread per output point id: the views that map it (won a pixel inside
+// the crop), as bit masks, and the block's numbers of view rows and pixels.
+__global__ __launch_bounds__(256) void ne_point_kernel(
+    const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ cnt, int V,
+    const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
+    unsigned *__restrict__ block_rows, i64 *__restrict__ block_pix, int *__restrict__ view_seen)
+{
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 i = q < num_points ? inv_ids[q] : -1;
+    unsigned rows = 0;
+    i64 pix = 0;
+    const int words = (V + 31) >> 5;
+    for (int wd = 0; wd < words; ++wd) {
+        unsigned sm = 0;
+        if (i >= 0) {
+            sm = seen_chunk(seen, seen_stride, i, 2 * wd);
+            if (32 * wd + 16 < V) sm |= seen_chunk(seen, seen_stride, i, 2 * wd + 1) << 16;
+        }
+        unsigned kept = 0;
+        while (sm) {
+            const int bit = __ffs(sm) - 1;
+            sm &= sm - 1;
+            const int v = (wd << 5) + bit;
+            view_seen[v] = 1;                       // mapped by the visibility model, cropped or not
+            const unsigned c = cnt[(size_t)i * V + v];
+            if (c) { kept |= 1u << bit; pix += c; }
+        }
+        if (q < num_points) masks[(size_t)wd * num_points + q] = kept;
+        rows += __popc(kept);
+    }
+    unsigned rows_total;
+    i64 pix_total;
+    block_exclusive_scan<unsigned>(rows, rows_total);
+    block_exclusive_scan<i64>(pix, pix_total);
+    if (threadIdx.x == 0) { block_rows[blockIdx.x] = rows_total; block_pix[blockIdx.x] = pix_total; }
+}
+
+// Pointers, images, view pointers and view features (mean over the view's
+// pixels, which all carry the features of the point, summed one by one as a
+// segment mean does); poff[i][v] <- first pixel of the pair for the pixel pass.
+__global__ __launch_bounds__(256) void ne_fill_kernel(
+    CloudSrc src, mvf_vis_params P, int V, const i64 *__restrict__ inv_ids, i64 num_points,
+    const unsigned *__restrict__ masks, const unsigned *__restrict__ block_rows,
+    const i64 *__restrict__ block_pix, const unsigned *__restrict__ cnt, const int *__restrict__ view_seen,
+    FeatArgs A, i64 out_capacity, i64 pix_capacity, i64 *__restrict__ pointers, i64 *__restrict__ images,
+    i64 *__restrict__ view_ptr, float *__restrict__ features, i64 *__restrict__ poff,
+    i64 *__restrict__ counters)
+{
+    extern __shared__ __align__(16) unsigned char dyn_lds[];   // V views, then V + 1 ranks
+    src = views_to_lds(src, V, (mvf_view *)dyn_lds);
+    int *view_rank = (int *)(dyn_lds + (size_t)V * sizeof(mvf_view));
+    for (int v = threadIdx.x; v <= V; v += 256) {
+        int r = 0;
+        for (int u = 0; u < v; ++u) r += view_seen[u] ? 1 : 0;
+        view_rank[v] = r;
+    }
+    i64 front_rows = 0, front_pix = 0;
+    for (unsigned k = threadIdx.x; k < blockIdx.x; k += 256) { front_rows += block_rows[k]; front_pix += block_pix[k]; }
+    i64 rows_before, pix_before;
+    block_exclusive_scan<i64>(front_rows, rows_before);
+    block_exclusive_scan<i64>(front_pix, pix_before);
+
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    const i64 i = q < num_points ? inv_ids[q] : -1;
+    const int words = (V + 31) >> 5;
+    unsigned rows = 0;
+    i64 pix = 0;
+    if (q < num_points)
+        for (int wd = 0; wd < words; ++wd) {
+            unsigned m = masks[(size_t)wd * num_points + q];
+            rows += __popc(m);
+            while (m) {
+                const int v = (wd << 5) + __ffs(m) - 1;
+                m &= m - 1;
+                pix += cnt[(size_t)i * V + v];
+            }
+        }
+    unsigned rows_total;
+    i64 pix_total;
+    i64 k = rows_before + block_exclusive_scan<unsigned>(rows, rows_total);
+    i64 p = pix_before + block_exclusive_scan<i64>(pix, pix_total);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const i64 n_rows = rows_before + rows_total, n_pix = pix_before + pix_total;
+        pointers[num_points] = n_rows;
+        if (n_rows <= out_capacity) view_ptr[n_rows] = n_pix;
+        counters[0] = n_rows;
+        counters[3] = view_rank[V];
+        counters[4] = n_pix;
+        if (n_rows > out_capacity) atomicOr((unsigned long long *)&counters[2], 1ull);
+        if (n_pix > pix_capacity) atomicOr((unsigned long long *)&counters[2], 4ull);
+    }
+    if (q >= num_points) return;
+    pointers[q] = k;
+    if (rows == 0) return;
+    const float px3 = src.xyz[3 * i], py3 = src.xyz[3 * i + 1], pz3 = src.xyz[3 * i + 2];
+    for (int wd = 0; wd < words; ++wd) {
+        unsigned m = masks[(size_t)wd * num_points + q];
+        while (m) {
+            const int v = (wd << 5) + __ffs(m) - 1;
+            m &= m - 1;
+            const unsigned c = cnt[(size_t)i * V + v];
+            poff[(size_t)i * V + v] = p;
+            if (k < out_capacity) {
+                double x, y, fx, fy; float d;
+                src.get(i, v, P, x, y, d, fx, fy);
+                float f[8];
+                write_features(f, A, i, px3, py3, pz3, src.views[v].img_xyz, d, y);
+                for (int j = 0; j < A.F; ++j) {
+                    float sum = f[j];
+                    for (unsigned t = 1; t < c; ++t) sum = __fadd_rn(sum, f[j]);
+                    features[(size_t)k * A.F + j] = __fdiv_rn(sum, (float)c);
+                }
+                images[k] = view_rank[v];
+                view_ptr[k] = p;
+            }
+            p += c;
+            ++k;
+        }
+    }
+}
+
 }  // namespace mvf
 
 using namespace mvf;
@@ -1400,13 +1588,13 @@ static int splat_visibility_impl(
     hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS_WIDE>), grid_m, block, 0, st, staged, staged_count, tiles_y,
                        (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     if (P.exact) {
-        hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+        hipLaunchKernelGGL((tile_zbuffer_kernel<0>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
                            seen, (i64)1, (unsigned *)nullptr);
         hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
                            P.crop_top, Hc, idmap);
     } else {
-        hipLaunchKernelGGL((tile_zbuffer_kernel<true>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+        hipLaunchKernelGGL((tile_zbuffer_kernel<1>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
                            (uint8_t *)nullptr, (i64)0, idmap);
     }
@@ -1509,8 +1697,12 @@ struct MapWorkspace {
     uint8_t *seen;
     CentreTable table;
     size_t clear_bytes, used;
+    // plain splat visibility only (map_pixels > 0): id map [V][W][Hc], pixel counts
+    // and first-pixel offsets of the (point, view) pairs [n][V], pixels per block
+    unsigned *idmap, *cnt;
+    i64 *poff, *block_pix;
     bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
-               i64 pair_capacity, i64 centre_slots)
+               i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0)
     {
         const i64 slots = centre_table_slots(centre_slots);
         int slots_log = 0;
@@ -1533,6 +1725,14 @@ struct MapWorkspace {
         seen = ar.take<uint8_t>((size_t)seen_stride * n);
         masks = ar.take<unsigned>((size_t)words * num_points);
         block_sums = ar.take<unsigned>(cdiv(num_points, 256));
+        idmap = cnt = nullptr;
+        poff = block_pix = nullptr;
+        if (map_pixels > 0) {
+            idmap = ar.take<unsigned>((size_t)map_pixels);
+            cnt = ar.take<unsigned>((size_t)n * V);
+            poff = ar.take<i64>((size_t)n * V);
+            block_pix = ar.take<i64>(cdiv(num_points, 256));
+        }
         used = ar.off;
         return ar.ok();
     }
@@ -1639,7 +1839,7 @@ extern "C" int mvf_map_images_exact(
     hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, staged, staged_count, tiles_y,
                        tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
     prof_mark("bin_fill", st);
-    hipLaunchKernelGGL((tile_zbuffer_kernel<false>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
+    hipLaunchKernelGGL((tile_zbuffer_kernel<0>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
                        seen, seen_stride, (unsigned *)nullptr);
     prof_mark("tile_zbuffer", st);
@@ -1701,7 +1901,7 @@ extern "C" int mvf_map_images_depth(
     if (!ar.ok()) { set_error("map_images_depth: workspace too small (%zu < %zu)", workspace_bytes, ar.off); return MVF_E_WORKSPACE; }
 
     prof_begin(st);
-    MVF_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(int64_t), st));
+    MVF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int64_t), st));
     MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int32_t), st));
     prof_mark("memset", st);
     CloudSrc src{xyz, views, mask, (i64)n, cylinder};
@@ -1717,6 +1917,94 @@ extern "C" int mvf_map_images_depth(
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
                        (i64 *)counters);
     prof_mark("csr_fill", st);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+// MapImages with SplattingVisibility(exact=False), all views in one launch set:
+// binning and tile z-buffer as in the exact pass, then every pixel a point wins
+// becomes a mapping (no shared-pixel rule, no centre table).
+extern "C" size_t mvf_map_images_splat_workspace_bytes(
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
+{
+    const i64 tiles = (i64)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    MapWorkspace ws;
+    ws.carve(nullptr, 0, n > 0 ? n : 1, V, tiles, num_points > 0 ? num_points : 1,
+             pair_capacity > 0 ? pair_capacity : 1, 1, (i64)V * W * H);
+    return ws.used;
+}
+
+extern "C" int mvf_map_images_splat(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
+    int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *linearity, const float *planarity, const float *scattering, const float *normals,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers, int64_t *images,
+    int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
+    int64_t pix_capacity, int32_t *view_seen, int64_t *counters, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_params(h_params, "map_images_splat")) return rc;
+    MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= MI_MAX_VIEWS,
+                "map_images_splat: bad sizes n=%lld V=%d (at most %d views per call)", (long long)n, V, MI_MAX_VIEWS);
+    MVF_REQUIRE(xyz && inv_ids && views && pointers && images && view_pointers && pixels && features &&
+                view_seen && counters, "map_images_splat: null buffer");
+    MVF_REQUIRE(crop_w >= 1 && crop_h >= 1 && pair_capacity >= 1 && out_capacity >= 0 && pix_capacity >= 0,
+                "map_images_splat: bad scalar argument");
+    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
+                "map_images_splat: pinhole cameras only");
+    const mvf_vis_params P = *h_params;
+    hipStream_t st = (hipStream_t)stream;
+    int tiles_x, tiles_y, Hc;
+    tile_grid(P, tiles_x, tiles_y, Hc);
+    const int tiles_per_view = tiles_x * tiles_y;
+    const i64 tiles = (i64)tiles_per_view * V;
+    const i64 nb = cdiv(num_points, 256);
+    MapWorkspace ws;
+    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, 1, (i64)V * P.W * Hc)) {
+        set_error("map_images_splat: workspace too small (%zu < %zu)", workspace_bytes, ws.used);
+        return MVF_E_WORKSPACE;
+    }
+    const i64 ncnt = ws.ncnt;
+
+    prof_begin(st);
+    MVF_HIP(hipMemsetAsync(ws.tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
+    prof_mark("memset", st);
+    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
+    dim3 grid_nv(cdiv(n, 256), V), block(256);
+    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
+                       tiles_per_view, ws.tile_count, ws.seen, ws.seen_stride, (i64 *)counters, view_seen, V,
+                       ws.staged, ws.staged_count);
+    prof_mark("bin_count", st);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, ws.tile_count, tiles,
+                       ws.tile_off, ws.tile_cur, ws.descs, ws.tile_count + ncnt, (i64 *)counters + 1, tiles_y,
+                       tiles_per_view);
+    prof_mark("tile_scan", st);
+    hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, ws.staged, ws.staged_count, tiles_y,
+                       tiles_per_view, ws.tile_off, ws.tile_cur, ws.entries, (i64)pair_capacity,
+                       (i64 *)counters + 2);
+    prof_mark("bin_fill", st);
+    hipLaunchKernelGGL((tile_zbuffer_kernel<2>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, ws.entries,
+                       ws.descs, ws.tile_count + ncnt, ws.tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity,
+                       tiles_y, tiles_per_view, P.W, Hc, ws.seen, ws.seen_stride, ws.idmap);
+    prof_mark("tile_zbuffer", st);
+    hipLaunchKernelGGL((ne_scan_kernel<false>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
+                       ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
+                       (const i64 *)nullptr, (int16_t *)nullptr, (i64)0);
+    prof_mark("pixel_count", st);
+    dim3 grid_q((unsigned)nb);
+    hipLaunchKernelGGL(ne_point_kernel, grid_q, block, 0, st, ws.seen, ws.seen_stride, ws.cnt, V,
+                       (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix, view_seen);
+    prof_mark("point_mask", st);
+    hipLaunchKernelGGL(ne_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st,
+                       src, P, V, (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix,
+                       ws.cnt, view_seen, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
+                       (i64)out_capacity, (i64)pix_capacity, (i64 *)pointers, (i64 *)images, (i64 *)view_pointers,
+                       features, ws.poff, (i64 *)counters);
+    prof_mark("csr_fill", st);
+    hipLaunchKernelGGL((ne_scan_kernel<true>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
+                       ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
+                       (const i64 *)ws.poff, pixels, (i64)pix_capacity);
+    prof_mark("pixel_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

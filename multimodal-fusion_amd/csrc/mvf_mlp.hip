@@ -266,7 +266,8 @@ __device__ __forceinline__ void mlp_store(
 // (-inf, the preset of the pool epilogue, is below every value in both views).
 __device__ __forceinline__ void atomic_max_float(float *p, float v)
 {
-    if (v >= 0.f) atomicMax((int *)p, __float_as_int(v));
+    // by the sign bit, not by value: -0.0 belongs to the negative branch
+    if (!(__float_as_uint(v) >> 31)) atomicMax((int *)p, __float_as_int(v));
     else atomicMin((unsigned *)p, __float_as_uint(v));
 }
 
@@ -932,7 +933,8 @@ __global__ __launch_bounds__(256) void csr_row_segments_kernel(
 // modality features copied out; zeros for an empty segment.
 __global__ __launch_bounds__(256) void segment_pick_kernel(
     const float *__restrict__ x_mod, int C, const float *__restrict__ feat, int ldf,
-    const i64 *__restrict__ ptr, i64 nseg, int pick_max, float *__restrict__ out)
+    const i64 *__restrict__ ptr, i64 nseg, int pick_max, float *__restrict__ out,
+    i64 *__restrict__ picked)
 {
     const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
     if (e >= nseg * C) return;
@@ -948,6 +950,9 @@ __global__ __launch_bounds__(256) void segment_pick_kernel(
             if (pick_max ? f > fb : f < fb) { fb = f; best = r; }
         }
         v = x_mod[(size_t)best * C + c];
+        if (picked && c == 0) picked[s] = best;
+    } else if (picked && c == 0) {
+        picked[s] = -1;
     }
     out[e] = v;
 }
@@ -1237,14 +1242,14 @@ extern "C" int mvf_csr_row_segments(const int64_t *ptr, int64_t nseg, int32_t *r
 
 extern "C" int mvf_segment_pick(
     const float *x_mod, int32_t C, const float *feat, int32_t ldf, const int64_t *ptr,
-    int64_t nseg, int32_t pick_max, float *out, void *stream)
+    int64_t nseg, int32_t pick_max, float *out, int64_t *picked, void *stream)
 {
     MVF_REQUIRE(nseg >= 0 && C >= 1 && ldf >= 1, "segment_pick: bad shape");
     if (nseg == 0) return MVF_OK;
     MVF_REQUIRE(x_mod && feat && ptr && out, "segment_pick: null buffer");
     hipLaunchKernelGGL(segment_pick_kernel, dim3(cdiv(nseg * C, 256)), dim3(256), 0,
                        (hipStream_t)stream, x_mod, C, feat, ldf, (const i64 *)ptr, (i64)nseg,
-                       pick_max, out);
+                       pick_max, out, (i64 *)picked);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

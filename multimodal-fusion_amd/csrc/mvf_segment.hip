@@ -364,6 +364,55 @@ __global__ __launch_bounds__(256) void sparse_interp_kernel(
     }
 }
 
+// Gradient of x[feature_map_indexing] with respect to x: row r's gradient is added
+// to the pixel it was read from (several rows may share a pixel, hence atomics;
+// the sum of a pixel's rows is order dependent in the last bits, as the
+// accumulating index_put of torch's own gather gradient is).  Lanes walk the
+// rows, so the channel planes are written with the access pattern the forward
+// read them with.
+__global__ __launch_bounds__(256) void scatter_features_kernel(
+    const float *__restrict__ grad, int C, int H, int W, const i64 *__restrict__ batch,
+    const int16_t *__restrict__ pixels, i64 rows, float *__restrict__ grad_x)
+{
+    const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const i64 r = (i64)blockIdx.x * 64 + row;
+    if (r >= rows) return;
+    const size_t hw = (size_t)H * W;
+    float *px = grad_x + (size_t)batch[r] * C * hw + (size_t)pixels[2 * r + 1] * W + pixels[2 * r];
+    for (int c = cq; c < C; c += 4) unsafeAtomicAdd(px + (size_t)c * hw, grad[(size_t)r * C + c]);
+}
+
+// Gradient of sparse_interpolation with respect to the feature maps: the four
+// weights of the forward, times the row's gradient, added to the four pixels.
+__global__ __launch_bounds__(256) void sparse_interp_backward_kernel(
+    const float *__restrict__ grad, int C, int H, int W, const float *__restrict__ coords,
+    const i64 *__restrict__ batch, i64 rows, int mode, float *__restrict__ grad_x)
+{
+    const int row = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const i64 r = (i64)blockIdx.x * 64 + row;
+    if (r >= rows) return;
+    const size_t hw = (size_t)H * W;
+    float *plane = grad_x + (size_t)batch[r] * C * hw;
+    const float p0 = __fadd_rn(__fmul_rn(coords[2 * r], (float)H), 0.5f);
+    const float p1 = __fadd_rn(__fmul_rn(coords[2 * r + 1], (float)W), 0.5f);
+    const float top = floorf(p0), bottom = floorf(__fadd_rn(p0, 1.0f));
+    const float left = floorf(p1), right = floorf(__fadd_rn(p1, 1.0f));
+    const float w_tl = fabsf(__fmul_rn(__fsub_rn(p0, bottom), __fsub_rn(p1, right)));
+    const float w_tr = fabsf(__fmul_rn(__fsub_rn(p0, bottom), __fsub_rn(p1, left)));
+    const float w_bl = fabsf(__fmul_rn(__fsub_rn(p0, top), __fsub_rn(p1, right)));
+    const float w_br = fabsf(__fmul_rn(__fsub_rn(p0, top), __fsub_rn(p1, left)));
+    const int t = unpad((int)top, H, mode), b = unpad((int)bottom, H, mode);
+    const int l = unpad((int)left, W, mode), rt = unpad((int)right, W, mode);
+    for (int c = cq; c < C; c += 4) {
+        const float g = grad[(size_t)r * C + c];
+        float *pc = plane + (size_t)c * hw;
+        if (t >= 0 && l >= 0) unsafeAtomicAdd(pc + (size_t)t * W + l, w_tl * g);
+        if (t >= 0 && rt >= 0) unsafeAtomicAdd(pc + (size_t)t * W + rt, w_tr * g);
+        if (b >= 0 && l >= 0) unsafeAtomicAdd(pc + (size_t)b * W + l, w_bl * g);
+        if (b >= 0 && rt >= 0) unsafeAtomicAdd(pc + (size_t)b * W + rt, w_br * g);
+    }
+}
+
 // Backward of segment_csr (the gradient torch_scatter attaches to it): one
 // thread per (segment, channel).  sum: every row of the segment receives the
 // segment's gradient; mean: divided by the row count; max / min: the FIRST row
@@ -582,6 +631,36 @@ extern "C" int mvf_sparse_interpolation(
     MVF_REQUIRE(x && coords && batch && out, "sparse_interpolation: null pointer");
     hipLaunchKernelGGL(sparse_interp_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
                        x, C, H, W, coords, (const i64 *)batch, (i64)rows, padding_mode, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_gather_features_backward(
+    const float *grad_out, int32_t B, int32_t C, int32_t H, int32_t W, const int64_t *batch,
+    const int16_t *pixels, int64_t rows, float *grad_x, void *stream)
+{
+    MVF_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && rows >= 0, "gather_features_backward: bad shape");
+    if (rows == 0) return MVF_OK;
+    MVF_REQUIRE(grad_out && batch && pixels && grad_x, "gather_features_backward: null pointer");
+    hipLaunchKernelGGL(scatter_features_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, C, H, W, (const i64 *)batch, pixels, (i64)rows, grad_x);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_sparse_interpolation_backward(
+    const float *grad_out, int32_t B, int32_t C, int32_t H, int32_t W, const float *coords,
+    const int64_t *batch, int64_t rows, int32_t padding_mode, float *grad_x, void *stream)
+{
+    MVF_REQUIRE(B >= 1 && C >= 1 && H >= 1 && W >= 1 && rows >= 0, "sparse_interpolation_backward: bad shape");
+    MVF_REQUIRE(padding_mode >= PAD_BORDER && padding_mode <= PAD_REFLECTION,
+                "sparse_interpolation_backward: unknown padding mode %d", padding_mode);
+    MVF_REQUIRE(padding_mode != PAD_REFLECTION || (H >= 2 && W >= 2),
+                "sparse_interpolation_backward: reflection padding needs H, W >= 2");
+    if (rows == 0) return MVF_OK;
+    MVF_REQUIRE(grad_out && coords && batch && grad_x, "sparse_interpolation_backward: null pointer");
+    hipLaunchKernelGGL(sparse_interp_backward_kernel, dim3(cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, C, H, W, coords, (const i64 *)batch, (i64)rows, padding_mode, grad_x);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -83,6 +83,10 @@ _SIGNATURES = {
     "mvf_map_images_exact": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P, _I32, _P, _P, _P,
                                        _P, _P, _I32, _I32, _I32, _I32, _I64, _I64,
                                        _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "mvf_map_images_splat_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I64, _I64]),
+    "mvf_map_images_splat": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P,
+                                       _I32, _I32, _I64, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P,
+                                       _SZ, _P]),
     "mvf_profile_zbuffer_ops": (C.c_int, [_P, _SZ, _I64, _I32, _P, _I64, _I64, _I64, _P, _P]),
     "mvf_map_images_depth_workspace_bytes": (_SZ, [_I64, _I32]),
     "mvf_map_images_depth": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P,
@@ -109,7 +113,9 @@ _SIGNATURES = {
     "mvf_attention_pool": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32,
                                      _I32, _I32, _I32, _F, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
     "mvf_csr_row_segments": (C.c_int, [_P, _I64, _P, _P]),
-    "mvf_segment_pick": (C.c_int, [_P, _I32, _P, _I32, _P, _I64, _I32, _P, _P]),
+    "mvf_segment_pick": (C.c_int, [_P, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "mvf_gather_features_backward": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _P]),
+    "mvf_sparse_interpolation_backward": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I32, _P, _P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -313,16 +313,44 @@ def attention_pool(x_mod, ptr, num_groups, chan2group, keys=None, queries=None,
     return out, comp, att, gate
 
 
-def segment_pick(x_mod, feat, ptr, pick_max):
+def _segment_pick(x_mod, feat, ptr, pick_max, want_rows=False):
     lib = L.load()
     dev = x_mod.device
     x_mod = x_mod.detach().float().contiguous()
     feat = feat.detach().float()
     nseg = ptr.shape[0] - 1
     out = torch.empty((nseg, x_mod.shape[1]), dtype=torch.float32, device=dev)
+    picked = torch.empty(nseg, dtype=torch.int64, device=dev) if want_rows else None
     if nseg > 0:
         with torch.cuda.device(dev):
             L.check(lib.mvf_segment_pick(
                 L.ptr(x_mod), x_mod.shape[1], L.ptr(feat), feat.stride(0), L.ptr(ptr), nseg,
-                int(bool(pick_max)), L.ptr(out), L.stream_ptr(dev)))
-    return out
+                int(bool(pick_max)), L.ptr(out), L.ptr(picked), L.stream_ptr(dev)))
+    return out, picked
+
+
+class _SegmentPick(torch.autograd.Function):
+    """Row selection per segment; the gradient goes to the selected rows."""
+
+    @staticmethod
+    def forward(ctx, x_mod, feat, ptr, pick_max):
+        out, picked = _segment_pick(x_mod, feat, ptr, pick_max, want_rows=True)
+        ctx.save_for_backward(picked)
+        ctx.shape = x_mod.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        picked, = ctx.saved_tensors
+        grad = torch.zeros(ctx.shape, dtype=grad_out.dtype, device=grad_out.device)
+        ok = picked >= 0
+        grad[picked[ok]] = grad_out[ok]          # one row per segment: no duplicates
+        return grad, None, None, None
+
+
+def segment_pick(x_mod, feat, ptr, pick_max):
+    """x_mod rows of the largest / smallest ``feat`` per segment; differentiable
+    with respect to x_mod."""
+    if torch.is_grad_enabled() and x_mod.requires_grad:
+        return _SegmentPick.apply(x_mod, feat, ptr, pick_max)
+    return _segment_pick(x_mod, feat, ptr, pick_max)[0]

@@ -36,6 +36,18 @@ def _prep(src, csr_idx):
     return src.detach().contiguous(), ptr
 
 
+def _wants_graph(module, *tensors):
+    """Does a forward of `module` on `tensors` have to record an autograd graph?
+    The fused inference kernels record none, so such a call takes the composed,
+    differentiable path (training.py) whatever the module's mode: in eval mode
+    BatchNorm then uses its running statistics there, as the reference does."""
+    if not torch.is_grad_enabled():
+        return False
+    if any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors):
+        return True
+    return any(p.requires_grad for p in module.parameters())
+
+
 class _SegmentCSR(torch.autograd.Function):
     """segment_csr with the gradient torch_scatter defines for it: sum / mean
     spread the segment's gradient over its rows, max / min route it to the first
@@ -222,71 +234,162 @@ def segment_softmax_csr(src, csr_idx, eps=1e-12, scaling=False):
     return out
 
 
+def _map_arrays(x, mappings):
+    """Checked device arrays of a mapping for a [B, C, H, W] feature map:
+    image of every view, view pointers, pixels, image of every pixel."""
+    if not x.is_cuda:
+        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise TypeError("expected a float32 [B, C, H, W] feature map")
+    dev = x.device
+    images = mappings.images.to(dev, torch.int64).contiguous()
+    vptr = mappings.atomic_csr_indexing.to(dev, torch.int64).contiguous()
+    pixels = mappings.pixels.to(dev, torch.int16).contiguous()
+    B, _, H, W = x.shape
+    if images.shape[0] and (
+            int(images.max()) >= B or int(pixels[:, 0].max()) >= W or int(pixels[:, 1].max()) >= H
+            or int(pixels.min()) < 0 or int(images.min()) < 0):
+        raise IndexError("mappings index outside the feature map")
+    return images, vptr, pixels
+
+
+def _gather_rows(x, batch, pixels):
+    rows = pixels.shape[0]
+    B, C_, H, W = x.shape
+    out = torch.empty((rows, C_), dtype=torch.float32, device=x.device)
+    if rows:
+        with torch.cuda.device(x.device):
+            L.check(L.load().mvf_gather_features(
+                L.ptr(x), B, C_, H, W, L.ptr(batch), L.ptr(pixels), rows, L.ptr(out),
+                L.stream_ptr(x.device)))
+    return out
+
+
+def _scatter_rows(grad_rows, shape, batch, pixels):
+    """Gradient of _gather_rows: a zero map of `shape` plus the rows at their pixels."""
+    B, C_, H, W = shape
+    grad_x = torch.zeros(shape, dtype=torch.float32, device=grad_rows.device)
+    rows = pixels.shape[0]
+    if rows:
+        g = grad_rows.detach().float().contiguous()
+        with torch.cuda.device(g.device):
+            L.check(L.load().mvf_gather_features_backward(
+                L.ptr(g), B, C_, H, W, L.ptr(batch), L.ptr(pixels), rows, L.ptr(grad_x),
+                L.stream_ptr(g.device)))
+    return grad_x
+
+
+class _GatherFeatures(torch.autograd.Function):
+    """x[feature_map_indexing]; gradient = scatter-add of the rows into the maps."""
+
+    @staticmethod
+    def forward(ctx, x, batch, pixels):
+        ctx.save_for_backward(batch, pixels)
+        ctx.shape = x.shape
+        return _gather_rows(x.detach().contiguous(), batch, pixels)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        batch, pixels = ctx.saved_tensors
+        return _scatter_rows(grad_out, ctx.shape, batch, pixels), None, None
+
+
+class _GatherAtomicPool(torch.autograd.Function):
+    """Fused gather + pixel -> view pool; the backward materialises the gathered
+    rows once to route the gradient like segment_csr does, then scatters it."""
+
+    @staticmethod
+    def forward(ctx, x, images, vptr, pixels, mode):
+        xd = x.detach().contiguous()
+        rows = images.shape[0]
+        B, C_, H, W = xd.shape
+        out = torch.empty((rows, C_), dtype=torch.float32, device=xd.device)
+        if rows:
+            with torch.cuda.device(xd.device):
+                L.check(L.load().mvf_gather_pool(
+                    L.ptr(xd), B, C_, H, W, L.ptr(images), L.ptr(vptr), L.ptr(pixels), rows,
+                    L.REDUCE[mode], L.ptr(out), L.stream_ptr(xd.device)))
+        ctx.mode, ctx.shape = mode, x.shape
+        ctx.save_for_backward(xd, images, vptr, pixels, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xd, images, vptr, pixels, out = ctx.saved_tensors
+        batch = images.repeat_interleave(vptr[1:] - vptr[:-1])
+        src = _gather_rows(xd, batch, pixels)
+        g = grad_out.detach().float().contiguous()
+        grad_rows = torch.zeros_like(src)
+        nseg, rows, C_ = vptr.shape[0] - 1, src.shape[0], src.shape[1]
+        if nseg > 0 and rows > 0:
+            with torch.cuda.device(g.device):
+                L.check(L.load().mvf_segment_csr_backward(
+                    L.ptr(g), L.ptr(src), L.ptr(out), rows, C_, L.ptr(vptr), nseg,
+                    L.REDUCE[ctx.mode], L.ptr(grad_rows), L.stream_ptr(g.device)))
+        return _scatter_rows(grad_rows, ctx.shape, batch, pixels), None, None, None, None
+
+
 def gather_atomic_pool(x, mappings, mode='max'):
     """``BimodalCSRPool(mode)(None, x[mappings.feature_map_indexing], None,
     mappings.atomic_csr_indexing)`` in one kernel: x is the [B, C, H, W] batch of
     image feature maps, ``mappings`` an ImageMapping whose pixels are at the
     resolution of x (core/multimodal/image.py:1272-1297, 1881-1902).  Returns the
-    view-level features [Vw, C]."""
-    if not x.is_cuda:
-        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
-    if x.dim() != 4 or x.dtype != torch.float32:
-        raise TypeError("gather_atomic_pool expects a float32 [B, C, H, W] feature map")
-    dev = x.device
-    x = x.detach().contiguous()
-    images = mappings.images.to(dev, torch.int64).contiguous()
-    vptr = mappings.atomic_csr_indexing.to(dev, torch.int64).contiguous()
-    pixels = mappings.pixels.to(dev, torch.int16).contiguous()
-    rows = images.shape[0]
-    B, C_, H, W = x.shape
-    if rows and (int(images.max()) >= B or int(pixels[:, 0].max()) >= W or int(pixels[:, 1].max()) >= H
-                 or int(pixels.min()) < 0 or int(images.min()) < 0):
-        raise IndexError("mappings index outside the feature map")
-    out = torch.empty((rows, C_), dtype=torch.float32, device=dev)
-    if rows:
-        lib = L.load()
-        with torch.cuda.device(dev):
-            L.check(lib.mvf_gather_pool(
-                L.ptr(x), B, C_, H, W, L.ptr(images), L.ptr(vptr), L.ptr(pixels), rows,
-                L.REDUCE[mode], L.ptr(out), L.stream_ptr(dev)))
-    return out
+    view-level features [Vw, C]; differentiable with respect to x."""
+    images, vptr, pixels = _map_arrays(x, mappings)
+    return _GatherAtomicPool.apply(x, images, vptr, pixels, mode)
 
 
 def gather_features(x, mappings):
     """``x[mappings.feature_map_indexing]`` for a [B, C, H, W] batch of feature
     maps (core/multimodal/image.py:1295, 1881-1895): one row of C features per
-    mapped pixel."""
-    if not x.is_cuda:
-        raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
-    if x.dim() != 4 or x.dtype != torch.float32:
-        raise TypeError("gather_features expects a float32 [B, C, H, W] feature map")
+    mapped pixel; differentiable with respect to x."""
+    _map_arrays(x, mappings)
     dev = x.device
-    x = x.detach().contiguous()
-    images = mappings.images.to(dev, torch.int64)
     pixels = mappings.pixels.to(dev, torch.int16).contiguous()
-    rows = pixels.shape[0]
-    B, C_, H, W = x.shape
-    if rows and (int(images.max()) >= B or int(pixels[:, 0].max()) >= W or int(pixels[:, 1].max()) >= H
-                 or int(pixels.min()) < 0 or int(images.min()) < 0):
-        raise IndexError("mappings index outside the feature map")
     batch = mappings.feature_map_indexing[0].to(dev).contiguous()
-    out = torch.empty((rows, C_), dtype=torch.float32, device=dev)
-    if rows:
-        lib = L.load()
-        with torch.cuda.device(dev):
-            L.check(lib.mvf_gather_features(
-                L.ptr(x), B, C_, H, W, L.ptr(batch), L.ptr(pixels), rows, L.ptr(out),
-                L.stream_ptr(dev)))
-    return out
+    return _GatherFeatures.apply(x, batch, pixels)
 
 
 _PADDING = {'border': 0, 'zeros': 1, 'reflection': 2}
 
 
+class _SparseInterpolation(torch.autograd.Function):
+    """Bilinear sampling; gradient = the same four weights scattered back."""
+
+    @staticmethod
+    def forward(ctx, x, coords, batch, mode):
+        xd = x.detach().float().contiguous()
+        n = coords.shape[0]
+        B, C_, H, W = xd.shape
+        out = torch.empty((n, C_), dtype=torch.float32, device=xd.device)
+        if n:
+            with torch.cuda.device(xd.device):
+                L.check(L.load().mvf_sparse_interpolation(
+                    L.ptr(xd), B, C_, H, W, L.ptr(coords), L.ptr(batch), n, mode, L.ptr(out),
+                    L.stream_ptr(xd.device)))
+        ctx.mode, ctx.shape, ctx.dtype = mode, x.shape, x.dtype
+        ctx.save_for_backward(coords, batch)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        coords, batch = ctx.saved_tensors
+        B, C_, H, W = ctx.shape
+        g = grad_out.detach().float().contiguous()
+        grad_x = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        if coords.shape[0]:
+            with torch.cuda.device(g.device):
+                L.check(L.load().mvf_sparse_interpolation_backward(
+                    L.ptr(g), B, C_, H, W, L.ptr(coords), L.ptr(batch), coords.shape[0], ctx.mode,
+                    L.ptr(grad_x), L.stream_ptr(g.device)))
+        return grad_x.to(ctx.dtype), None, None, None
+
+
 def sparse_interpolation(features, coords, batch, padding_mode='border'):
     """Bilinear interpolation of a batch of feature maps [B, C, H, W] at the
     [N, 2] coordinates ``coords`` (row, column, both in [0, 1]) of the maps
-    ``batch`` [N] (core/multimodal/image.py:105-170).  Returns [N, C]."""
+    ``batch`` [N] (core/multimodal/image.py:105-170).  Returns [N, C];
+    differentiable with respect to the feature maps."""
     assert len(features.shape) == 4
     assert coords.shape[0] == batch.shape[0]
     assert len(coords.shape) == 2 and coords.shape[1] == 2
@@ -295,24 +398,16 @@ def sparse_interpolation(features, coords, batch, padding_mode='border'):
     if not features.is_cuda:
         raise RuntimeError("mvfusion pooling runs on a HIP device only (there is no CPU fallback).")
     dev = features.device
-    x = features.detach().float().contiguous()
-    coords = coords.to(dev, torch.float32).contiguous()
+    coords = coords.detach().to(dev, torch.float32).contiguous()
     batch = batch.to(dev, torch.int64).contiguous()
     n = coords.shape[0]
-    B, C_, H, W = x.shape
+    B = features.shape[0]
     if n:
         assert 0 <= coords.min()
         assert coords.max() <= 1
         if int(batch.max()) >= B or int(batch.min()) < 0:
             raise IndexError("batch index outside the feature maps")
-    out = torch.empty((n, C_), dtype=torch.float32, device=dev)
-    if n:
-        lib = L.load()
-        with torch.cuda.device(dev):
-            L.check(lib.mvf_sparse_interpolation(
-                L.ptr(x), B, C_, H, W, L.ptr(coords), L.ptr(batch), n, _PADDING[padding_mode],
-                L.ptr(out), L.stream_ptr(dev)))
-    return out
+    return _SparseInterpolation.apply(features, coords, batch, _PADDING[padding_mode])
 
 
 def group_sizes(num_elements, num_groups):
@@ -477,7 +572,7 @@ class MinMaxDiffSetFeat(nn.Module, ABC):
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
-        if self.training:
+        if self.training or _wants_graph(self, x):
             from . import training
             return training.min_max_diff_set_feat(self, x, ptr)
         return self.embed(x, ptr, None)
@@ -540,7 +635,7 @@ class DeepSetFeat(nn.Module, ABC):
 
     def forward(self, x, csr_idx):
         ptr = _device_ptr(x, csr_idx)
-        if self.training:
+        if self.training or _wants_graph(self, x):
             from . import training
             return training.deep_set_feat(self, x, ptr)
         return self.embed(x, ptr, None)
@@ -563,7 +658,7 @@ class MLPSetFeat(nn.Module, ABC):
         return _dense.run_layers(_dense.mlp_layers(self.mlp) + list(tail), x, dot=dot)
 
     def forward(self, x, csr_idx):
-        if self.training:
+        if self.training or _wants_graph(self, x):
             from . import training
             return training.mlp(self.mlp, x)
         return self.embed(x, None, None)
@@ -572,7 +667,9 @@ class MLPSetFeat(nn.Module, ABC):
 class Gating(nn.Module):
     """Rectified-tanh gating mechanism with learnable linear correction
     (pooling.py:702-727).  Inside the pools the gate is evaluated by the
-    attention kernel; this forward serves direct calls."""
+    attention kernel; this forward serves direct calls.  As in the reference,
+    ``activation`` is recorded but the forward always applies tanh(relu(x))
+    (pooling.py:717-723)."""
 
     def __init__(self, num_groups, weight=True, bias=True, activation='tanh+'):
         super(Gating, self).__init__()
@@ -588,7 +685,7 @@ class Gating(nn.Module):
             x = x * self.weight
         if self.bias is not None:
             x = x + self.bias
-        x = torch.tanh(torch.relu(x)) if self._activation == 'tanh+' else torch.sigmoid(x)
+        x = torch.tanh(torch.relu(x))
         return x.view(-1, self.num_groups).squeeze(1)
 
     def extra_repr(self) -> str:
@@ -617,13 +714,10 @@ class _AttentivePool(nn.Module, ABC):
             cache[key] = c2g.to(device=device, dtype=torch.int32)
         return cache[key]
 
-    def _check_mode(self):
-        if self.G is not None and self.G._activation != 'tanh+' and not self.training:
-            raise NotImplementedError("the attention kernel implements the 'tanh+' gate only")
-
     def _forward_train(self, composed, x_main, x_mod, x_map, csr_idx):
-        """Training mode: differentiable composition (training.py) instead of
-        the fused inference kernels."""
+        """Training mode, or any call that must record an autograd graph:
+        differentiable composition (training.py) instead of the fused inference
+        kernels."""
         ptr = _device_ptr(x_mod, csr_idx)
         x_pool, parts = composed(self, x_main, x_mod, x_map, ptr)
         if self.save_last:
@@ -684,8 +778,7 @@ class GroupBimodalCSRPool(_AttentivePool):
         :param csr_idx:
         :return: x_pool
         """
-        self._check_mode()
-        if self.training:
+        if self.training or _wants_graph(self, x_main, x_mod, x_map):
             from . import training
             return self._forward_train(training.group_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)
@@ -790,8 +883,7 @@ class QKVBimodalCSRPool(_AttentivePool):
         :param csr_idx:
         :return: x_pool
         """
-        self._check_mode()
-        if self.training:
+        if self.training or _wants_graph(self, x_main, x_mod, x_map):
             from . import training
             return self._forward_train(training.qkv_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)

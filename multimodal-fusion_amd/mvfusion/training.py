@@ -1,9 +1,11 @@
-"""Training-mode forward of the attentive pools and their set encoders.
+"""Differentiable forward of the attentive pools and their set encoders.
 
-In ``.eval()`` the pools run through the fused MFMA layer-chain and attention
-kernels (``dense.py``), which implement BatchNorm with running statistics and
-record no autograd graph.  In ``.train()`` they are composed here from
-differentiable pieces instead: the dense layers (Linear, BatchNorm1d with batch
+Calls that need no autograd graph (``.eval()`` under ``torch.no_grad()``, or
+nothing requiring a gradient) run through the fused MFMA layer-chain and
+attention kernels (``dense.py``), which implement BatchNorm with running
+statistics and record no graph.  In ``.train()``, and in ``.eval()`` whenever an
+input or a parameter requires a gradient, the pools are composed here from
+differentiable pieces instead (BatchNorm follows the module's mode): the dense layers (Linear, BatchNorm1d with batch
 statistics, LeakyReLU) are torch modules on the HIP device, the CSR operations
 are this package's kernels wrapped in ``torch.autograd.Function``
 (``pooling.segment_csr`` / ``gather_csr`` / ``segment_softmax_csr``).  The
@@ -77,9 +79,8 @@ def attend(m, x_mod, comp, ptr):
 def group_pool(m, x_main, x_mod, x_map, ptr):
     x_map = map_encoder(m.E_map, x_map, ptr)
     x_mod = mlp(m.E_mod, x_mod)
-    if m.use_mod:
-        x_map = mlp(m.E_mix, torch.cat([x_map, x_mod], dim=1))
-    comp = m.E_score(x_map)
+    x_mix = mlp(m.E_mix, torch.cat([x_map, x_mod], dim=1)) if m.use_mod else x_map
+    comp = m.E_score(x_mix)
     x_pool, att, gate = attend(m, x_mod, comp, ptr)
     return x_pool, dict(x_map=x_map, x_mod=x_mod, C=comp, A=att, G=gate)
 

@@ -4,11 +4,13 @@ interface of ``torch_points3d/core/data_transform/multimodal/image.py``
 
 Two execution plans, same results as the reference's CPU path:
 
-* fused (``SplattingVisibility`` with ``exact=True``, pinhole cameras, integer
-  ``proj_upscale`` / ``downscale``, distinct mapping ids -- the shipped
-  KITTI-360 / WildScenes configuration): every view of the sample goes through
-  one launch set of ``mvf_map_images_exact`` which also assembles the nested
-  CSR on the device; nothing is sorted.
+* fused (pinhole cameras, distinct mapping ids; ``SplattingVisibility`` with
+  ``exact=True`` and integer ``proj_upscale`` / ``downscale`` -- the shipped
+  KITTI-360 / WildScenes configuration --, with ``exact=False`` at the images'
+  own resolution, or ``DepthBasedVisibility`` with decoded depth maps): every
+  view of the sample goes through one launch set (``mvf_map_images_exact``,
+  ``mvf_map_images_splat``, ``mvf_map_images_depth``) which also assembles the
+  nested CSR on the device; nothing is sorted.
 * per view (anything else the HIP kernels support): the reference's own loop --
   visibility model, pixel conversion, duplicate removal, ``from_dense`` -- with
   each step on the device.
@@ -139,7 +141,7 @@ class FusedMapPlan:
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
-                 lane=0, centre_slots=None, depth_maps=None):
+                 lane=0, centre_slots=None, depth_maps=None, pix_cap=None):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
         # [V, W, H] float32 depth maps: the pass then runs DepthBasedVisibility
         # (mvf_map_images_depth) instead of the exact splat visibility
@@ -154,6 +156,10 @@ class FusedMapPlan:
         # slots of the table that resolves shared centre pixels (the library
         # rounds up to a power of two); fitted to the mappings after a run
         self.centre_slots = centre_slots or max(self.N * V // 8, 65536)
+        # plain splat visibility (params.exact == 0): every pixel a point wins is
+        # a mapping; room for that many pixels (at most one per image pixel)
+        self.splat = depth_maps is None and not params.exact
+        self.pix_cap = pix_cap or (V * params.W * params.H // 2)
         self._slots = [None] * self.SLOTS
         self._ws = None
         self._turn = 0
@@ -167,24 +173,27 @@ class FusedMapPlan:
             self.pos, self.ids, self.inv, self.attrs, self.views, self.mask, self.params,
             self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
             self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane,
-            centre_slots=self.centre_slots, depth_maps=self.depth_maps)
+            centre_slots=self.centre_slots, depth_maps=self.depth_maps, pix_cap=self.pix_cap)
 
     def _slot(self, k):
-        """Output buffers of slot k: (out_cap, counters, host counters, event,
-        pointers, view_seen, images, pixels, features)."""
+        """Output buffers of slot k: (capacities, counters, host counters, event,
+        pointers, view_seen, images, pixels, features, view pointers)."""
         sl = self._slots[k]
-        if sl is None or sl[0] != self.out_cap:
+        caps = (self.out_cap, self.pix_cap if self.splat else 0)
+        if sl is None or sl[0] != caps:
             d = self.device
             keep = sl[1:4] if sl is not None else (
-                torch.zeros(4, dtype=torch.int64, device=d),
-                torch.zeros(4, dtype=torch.int64).pin_memory(),
+                torch.zeros(8, dtype=torch.int64, device=d),
+                torch.zeros(8, dtype=torch.int64).pin_memory(),
                 torch.cuda.Event())
-            sl = (self.out_cap,) + tuple(keep) + (
+            n_pix = self.pix_cap if self.splat else self.out_cap
+            sl = (caps,) + tuple(keep) + (
                 torch.empty(self.num_points + 1, dtype=torch.int64, device=d),
                 torch.empty(self.V, dtype=torch.int32, device=d),
                 torch.empty(self.out_cap, dtype=torch.int64, device=d),
-                torch.empty((self.out_cap, 2), dtype=torch.int16, device=d),
-                torch.empty((self.out_cap, self.F), dtype=torch.float32, device=d))
+                torch.empty((n_pix, 2), dtype=torch.int16, device=d),
+                torch.empty((self.out_cap, self.F), dtype=torch.float32, device=d),
+                torch.empty(self.out_cap + 1, dtype=torch.int64, device=d) if self.splat else None)
             self._slots[k] = sl
         return sl
 
@@ -194,6 +203,9 @@ class FusedMapPlan:
             lib = L.load()
             if self.depth_maps is not None:
                 ws_bytes = lib.mvf_map_images_depth_workspace_bytes(self.num_points, self.V)
+            elif self.splat:
+                ws_bytes = lib.mvf_map_images_splat_workspace_bytes(
+                    self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
             else:
                 ws_bytes = lib.mvf_map_images_workspace_bytes(
                     self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
@@ -207,8 +219,19 @@ class FusedMapPlan:
         lib = L.load()
         P = self.params
         sl = self._slot(slot)
-        _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = sl
+        _, counters, _, _, pointers, view_seen, img_ids, pixels, feats, view_ptr = sl
         ws = self._workspace()
+        if self.splat:
+            assert self.upscale == 1 and self.downscale == 1
+            with torch.cuda.device(self.device):
+                L.check(lib.mvf_map_images_splat(
+                    L.ptr(self.pos), L.ptr(self.inv), self.N, self.num_points, L.ptr(self.views),
+                    self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
+                    *[L.ptr(a) for a in self.attrs], int(self.crop_size[0]), int(self.crop_size[1]),
+                    self.pair_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(view_ptr), L.ptr(pixels),
+                    L.ptr(feats), self.out_cap, self.pix_cap, L.ptr(view_seen), L.ptr(counters),
+                    L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
+            return sl
         if self.depth_maps is not None:
             with torch.cuda.device(self.device):
                 L.check(lib.mvf_map_images_depth(
@@ -252,27 +275,39 @@ class FusedMapPlan:
         if pow2(target) != pow2(self.centre_slots):
             self.centre_slots = target
 
-    def _grow(self, n_map, pairs, overflow=1):
+    def _grow(self, n_map, pairs, overflow=1, n_pix=0):
         """Larger buffers after an overflow (bit 0: pairs / outputs, bit 1: the
-        centre-pixel table)."""
+        centre-pixel table, bit 2: pixels of the plain splat mode)."""
         if overflow & 1:
             self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
             self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
         if overflow & 2:
             self.centre_slots = max(4 * self.centre_slots, 4 * n_map)
+        if overflow & 4:
+            self.pix_cap = max(self.pix_cap, int(n_pix * 1.1) + 4096)
+
+    def _outputs(self, sl, n_map, n_pix):
+        """The sliced outputs of a finished pass: pointers, images, pixels,
+        features, view_seen (and, in the plain splat mode, the view pointers)."""
+        _, _, _, _, pointers, view_seen, img_ids, pixels, feats, view_ptr = sl
+        if self.splat:
+            return (pointers, img_ids[:n_map], pixels[:n_pix], feats[:n_map], view_seen,
+                    view_ptr[:n_map + 1])
+        return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
 
     def run(self):
         """Mapping pass + read-back of the data-dependent sizes (one
         synchronisation); repeats with larger buffers after an overflow.
-        Returns pointers, images, pixels, features, view_seen."""
+        Returns pointers, images, pixels, features, view_seen (and the view
+        pointers in the plain splat mode)."""
         for _ in range(4):
-            _, counters, _, _, pointers, view_seen, img_ids, pixels, feats = self.launch(0)
-            n_map, pairs, overflow, n_seen = counters.tolist()
-            self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
+            sl = self.launch(0)
+            n_map, pairs, overflow, n_seen, n_pix = sl[1].tolist()[:5]
+            self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix)
             if not overflow:
                 self._fit(n_map)
-                return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
-            self._grow(n_map, pairs, overflow)
+                return self._outputs(sl, n_map, n_pix)
+            self._grow(n_map, pairs, overflow, n_pix)
         raise L.MvfError("MapImages: buffers still too small after retries")
 
 
@@ -284,17 +319,17 @@ class PendingMap:
 
     def result(self):
         """Waits for the sizes of this pass (not for later work on the stream)
-        and returns pointers, images, pixels, features, view_seen.  After an
-        overflow the pass is repeated synchronously with larger buffers."""
-        _, _, host, event, pointers, view_seen, img_ids, pixels, feats = self._slot
+        and returns what FusedMapPlan.run returns.  After an overflow the pass
+        is repeated synchronously with larger buffers."""
+        host, event = self._slot[2], self._slot[3]
         event.synchronize()
-        n_map, pairs, overflow, n_seen = host.tolist()
+        n_map, pairs, overflow, n_seen, n_pix = host.tolist()[:5]
         if overflow:
-            self.plan._grow(n_map, pairs, overflow)
+            self.plan._grow(n_map, pairs, overflow, n_pix)
             return self.plan.run()
-        self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen)
+        self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix)
         self.plan._fit(n_map)
-        return pointers, img_ids[:n_map], pixels[:n_map], feats[:n_map], view_seen
+        return self.plan._outputs(self._slot, n_map, n_pix)
 
 
 class MapImages(ImageTransform):
@@ -347,9 +382,10 @@ class MapImages(ImageTransform):
         return order
 
     def _fusable(self, images, visi_model):
-        """Can all views of these images go through one launch set?  Exact splat
-        visibility or depth-map visibility (with the decoded maps at hand as
-        ``images.depth_maps``), pinhole cameras, integer scale factors."""
+        """Can all views of these images go through one launch set?  Splat
+        visibility (exact, or plain at the images' own resolution) or depth-map
+        visibility (with the decoded maps at hand as ``images.depth_maps``),
+        pinhole cameras, integer scale factors."""
         ints = all(float(s).is_integer() and s >= 1
                    for s in (images.proj_upscale, images.downscale))
         common = (visi_model.camera in ('kitti360_perspective', 'scannet')
@@ -357,8 +393,12 @@ class MapImages(ImageTransform):
                   and images.is_pinhole and images.has_extrinsic
                   and images.num_views <= 480)
         if self.method == 'SplattingVisibility':
-            return (common and bool(visi_model.exact)
-                    and images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1)
+            small = images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1
+            if visi_model.exact:
+                return common and small
+            # plain splat visibility: other scale factors merge pixels of a point,
+            # which the per-view path resolves with its duplicate removal
+            return common and small and images.proj_upscale == 1 and images.downscale == 1
         if self.method == 'DepthBasedVisibility':
             return common and getattr(images, 'depth_maps', None) is not None
         return False
@@ -428,11 +468,11 @@ class MapImages(ImageTransform):
             current.wait_stream(s)
         data_out, images_out = [], []
         for (data, images, visi_model, _), res in zip(staged, results):
-            pointers, img_ids, pixels, feats, view_seen = res
+            pointers, img_ids, pixels, feats, view_seen = res[:5]
             if img_ids.shape[0] == 0:
                 raise ValueError(_NO_MAPPING_MSG)
             in_device = images.device
-            mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)
+            mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats, *res[5:])
             seen = torch.where(view_seen > 0)[0]
             if seen.shape[0] != images.num_views:
                 images = images[seen.to(in_device)]
@@ -561,13 +601,14 @@ class MapImages(ImageTransform):
         if plan is None:
             return None
         t1 = time.perf_counter()
-        pointers, img_ids, pixels, feats, view_seen = plan.run()
+        res = plan.run()
+        pointers, img_ids, pixels, feats, view_seen = res[:5]
         t2 = time.perf_counter()
         self._pair_cap, self._out_cap = plan.pair_cap, plan.out_cap
         self._centre_slots = plan.centre_slots
         if img_ids.shape[0] == 0:
             raise ValueError(_NO_MAPPING_MSG)
-        mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats)
+        mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats, *res[5:])
         seen = torch.where(view_seen > 0)[0]
         self.timings['t_stage'] = (t1 - t0) * 1e3 - self.timings['t_sphere_sampling']
         self.timings['t_visibility'] = (t2 - t1) * 1e3

@@ -13,6 +13,15 @@ from mvfusion import pooling
 import mvf_oracle as orc
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_calls():
+    """The tests of this file exercise the fused inference kernels: eval mode
+    with autograd off (with autograd on, eval-mode calls whose parameters require
+    a gradient take the differentiable composed path instead)."""
+    with torch.no_grad():
+        yield
 DEV = "cuda:0"
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
@@ -188,10 +197,12 @@ def test_training_mode_records_a_graph_and_cpu_inputs_raise():
     mod = pooling.QKVBimodalCSRPool(in_main=4, in_map=4, in_mod=4).to(DEV)
     x = torch.rand(6, 4, device=DEV)
     ptr = torch.tensor([0, 2, 2, 6], device=DEV)
-    out = mod(x[:3], x, x, ptr)                     # modules start in training mode
-    assert out.shape == (3, 4) and out.requires_grad
-    with torch.no_grad():
-        assert not mod.eval()(x[:3], x, x, ptr).requires_grad
+    with torch.enable_grad():
+        out = mod(x[:3], x, x, ptr)                 # modules start in training mode
+        assert out.shape == (3, 4) and out.requires_grad
+        # eval mode with autograd on and parameters that require a gradient: a graph too
+        assert mod.eval()(x[:3], x, x, ptr).requires_grad
+    assert not mod.eval()(x[:3], x, x, ptr).requires_grad
     with pytest.raises(RuntimeError):
         mod.eval()(x[:3].cpu(), x.cpu(), x.cpu(), ptr.cpu())
 

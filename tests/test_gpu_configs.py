@@ -12,6 +12,15 @@ from mvfusion import synthetic as S
 from test_gpu_parity import VIS, Data, check_mapping, make_inputs, npy
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_calls():
+    """Forward-only workloads: autograd off, so that eval-mode attentive pools
+    run their fused inference kernels."""
+    with torch.no_grad():
+        yield
+
 T = torch.from_numpy
 DEV = torch.device("cuda", 0)
 
@@ -254,19 +263,77 @@ def test_map_images_repeated_mapping_ids():
 
 def test_c2_non_exact_splat_visibility_full_size():
     """The WildScenes-shaped scan with exact=False (plain splat visibility: every
-    pixel a point wins is a mapping) through MapImages, against the oracle."""
+    pixel a point wins is a mapping), all 16 views in one launch set, against the
+    oracle's per-view loop: 32 M pixels in 319 k views; then the pixel -> view ->
+    point pools over them."""
+    from mvfusion.pooling import segment_csr_two_level
     from mvfusion.transforms import MapImages
-    sc = S.make_scene("c2", seed=2, n_views=4)
+    sc = S.make_scene("c2", seed=2)
     xyz = sc["xyz"]
     N = xyz.shape[0]
-    assert N == 300_000
+    assert N == 300_000 and sc["pos"].shape[0] == 16
     ref = orc.map_images(xyz, np.arange(N), sc, order=None, ref_size=sc["img_size"], cylinder=True,
                          exact=False, **VIS)
     data, images = make_inputs(xyz, np.arange(N), sc, sc["img_size"], attrs=False)
     t = MapImages(method="SplattingVisibility", cylinder=True, exact=False, point_order="index", **VIS)
+    assert t._fusable(images, t._settle(data, images))
     _, out = t(data, images)
-    assert ref["pixels"].shape[0] > 1_000_000
+    assert ref["pixels"].shape[0] > 30_000_000
+    m = out.mappings
+    check_mapping(m, ref)
+    # the fused pass emits the pixels of a view in ascending (x, y) order already
+    px = npy(m.pixels).astype(np.int64)
+    key = px[:, 0] * 65536 + px[:, 1]
+    seg = np.repeat(np.arange(ref["view_pointers"].shape[0] - 1), np.diff(ref["view_pointers"]))
+    assert np.all((np.diff(key) > 0) | (np.diff(seg) > 0))
+    rng = np.random.default_rng(6)
+    x_pix = rng.random((px.shape[0], 3), dtype=np.float32)
+    g_max, g_mean = segment_csr_two_level(T(x_pix).to(DEV), m.atomic_csr_indexing.to(DEV),
+                                          m.view_csr_indexing.to(DEV), inner="max", outer=("max", "mean"))
+    xv = orc.segment_csr(x_pix, ref["view_pointers"], "max")
+    assert np.array_equal(npy(g_max), orc.segment_csr(xv, ref["pointers"], "max"))
+    np.testing.assert_allclose(npy(g_mean), orc.segment_csr(xv, ref["pointers"], "mean"), rtol=1e-5, atol=0)
+
+
+def test_non_exact_fused_options_and_overflow():
+    """Plain splat visibility on the fused path with an image mask, crops, crop
+    offsets and a crop window smaller than the image (pairs whose pixels are all
+    cropped away vanish, their view still counts as seen), mapping features from
+    point attributes; then the same pass from deliberately small buffers."""
+    from mvfusion import visibility as visibility_module
+    from mvfusion.images import SameSettingImageData
+    from mvfusion.transforms import MapImages, kdtree_order
+    sc = S.make_scene("c1", seed=79, n_points=30000, n_views=5)
+    xyz = sc["xyz"]
+    N = xyz.shape[0]
+    W, H = sc["img_size"]
+    rng = np.random.default_rng(2)
+    mask = rng.random((W, H)) > 0.2
+    vis = dict(VIS, exact=False, r_min=1.0, crop_top=30, crop_bottom=20)
+    offs = np.array([[40 * k, 5 * k] for k in range(5)], np.int64)
+    crop_size = (W - 400, H - 60)
+    order = kdtree_order(T(xyz), True).numpy()
+    nrm, lin, pla, sca = S.surface_normals(xyz)
+    ref = orc.map_images(xyz, np.arange(N), sc, order=order, ref_size=(W, H), cylinder=True,
+                         img_mask=mask, crop_size=crop_size, crop_offsets=offs, linearity=lin,
+                         planarity=pla, scattering=sca, normals=nrm, **vis)
+    data, _ = make_inputs(xyz, np.arange(N), sc, (W, H), attrs=True, order=order)
+    images = SameSettingImageData(
+        pos=T(sc["pos"]), extrinsic=T(sc["extrinsic"]), fx=T(sc["fx"]), fy=T(sc["fy"]), mx=T(sc["mx"]),
+        my=T(sc["my"]), ref_size=(W, H), proj_upscale=1, mask=T(mask), crop_size=crop_size,
+        crop_offsets=T(offs))
+    t = MapImages(method="SplattingVisibility", cylinder=True, **vis)
+    model = t._settle(data, images)
+    assert t._fusable(images, model)
+    _, out = t(data, images)
+    assert np.diff(ref["view_pointers"]).max() > 4 and ref["images"].shape[0] > 500
     check_mapping(out.mappings, ref)
+    plan = t.prepare_fused(data, images, model, DEV)
+    plan.out_cap, plan.pair_cap, plan.pix_cap = 16, 16, 16
+    res = plan.run()
+    assert plan.pix_cap >= ref["pixels"].shape[0] and plan.out_cap >= ref["images"].shape[0]
+    from mvfusion.mapping import ImageMapping
+    check_mapping(ImageMapping.from_csr_arrays(res[0], res[1], res[2], res[3], res[5]), ref)
 
 
 def test_view_sharded_scene_equals_single_pass():
@@ -429,7 +496,8 @@ def test_view_sharded_attentive_pool_equals_single_pass():
     pool = pooling.QKVBimodalCSRPool(in_main=8, in_map=xm.shape[1], in_mod=C_feat, out_mod=C_feat,
                                      num_groups=1, nc_qk=8, gating=False).to(DEV).eval()
     x_main = T(rng.random((N, 8)).astype(np.float32)).to(DEV)
-    want = pool(x_main, xv, xm, ptr)
+    with torch.no_grad():
+        want = pool(x_main, xv, xm, ptr)
     assert float(want.abs().max()) > 0
     parts = [run(D.partition_views(V, r, 2)) for r in range(2)]
     outs = []

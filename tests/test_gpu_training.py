@@ -93,3 +93,106 @@ def test_differentiable_csr_primitives():
     want = np.zeros_like(src, dtype=np.float64)
     np.add.at(want, seg, w.astype(np.float64))
     assert close(sg.grad.cpu().numpy(), want, 1e-5)
+
+
+def test_feature_map_gathers_are_differentiable():
+    """Gradients of the feature-map gathers with respect to the image feature maps
+    (what reaches the 2D encoder): x[feature_map_indexing], the fused gather +
+    pixel -> view pool and the bilinear sparse_interpolation, against torch's own
+    autograd through plain indexing."""
+    from mvfusion import pooling
+    from mvfusion.mapping import ImageMapping
+    rng = np.random.default_rng(3)
+    B, C, H, W, n_pts = 3, 7, 20, 24, 50
+    # a few points, up to 3 views each, 1 to 4 pixels per view; pixels repeat across views
+    point_ids, image_ids, pix = [], [], []
+    for pt in range(n_pts):
+        for im in rng.choice(B, size=rng.integers(0, 4), replace=False):
+            for _ in range(rng.integers(1, 5)):
+                point_ids.append(pt); image_ids.append(im)
+                pix.append([rng.integers(0, 6), rng.integers(0, 5)])        # few pixels: many collisions
+    m = ImageMapping.from_dense(
+        T(np.asarray(point_ids)).cuda(), T(np.asarray(image_ids)).cuda(),
+        T(np.asarray(pix, np.int16)).cuda(), T(rng.random((len(pix), 2)).astype(np.float32)).cuda(),
+        num_points=n_pts)
+    x0 = T(rng.normal(size=(B, C, H, W)).astype(np.float32)).cuda()
+    idx = m.feature_map_indexing
+
+    # plain gather
+    w = T(rng.normal(size=(m.pixels.shape[0], C)).astype(np.float32)).cuda()
+    xa = x0.clone().requires_grad_(True)
+    (pooling.gather_features(xa, m) * w).sum().backward()
+    xb = x0.clone().requires_grad_(True)
+    (xb[idx] * w).sum().backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    assert float(xa.grad.abs().max()) > 0
+
+    # fused gather + atomic pool, every reduction
+    vptr = m.atomic_csr_indexing
+    wv = T(rng.normal(size=(vptr.shape[0] - 1, C)).astype(np.float32)).cuda()
+    for mode in ("max", "min", "sum", "mean"):
+        xa = x0.clone().requires_grad_(True)
+        out = pooling.gather_atomic_pool(xa, m, mode)
+        (out * wv).sum().backward()
+        xb = x0.clone().requires_grad_(True)
+        ref = pooling.segment_csr(xb[idx], vptr, reduce=mode)
+        (ref * wv).sum().backward()
+        torch.testing.assert_close(out, ref, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+
+    # bilinear interpolation against a torch composition of the same four taps
+    n = 300
+    coords = T(rng.random((n, 2)).astype(np.float32)).cuda()
+    batch = T(rng.integers(0, B, n)).cuda()
+    wi = T(rng.normal(size=(n, C)).astype(np.float32)).cuda()
+    xa = x0.clone().requires_grad_(True)
+    got = pooling.sparse_interpolation(xa, coords, batch, padding_mode="border")
+    (got * wi).sum().backward()
+    xb = x0.clone().requires_grad_(True)
+    xp = torch.nn.ReplicationPad2d(1)(xb)
+    p0, p1 = coords[:, 0] * H + 0.5, coords[:, 1] * W + 0.5
+    top, bottom, left, right = p0.floor(), (p0 + 1).floor(), p1.floor(), (p1 + 1).floor()
+    taps = ((top, left, (p0 - bottom) * (p1 - right)), (top, right, (p0 - bottom) * (p1 - left)),
+            (bottom, left, (p0 - top) * (p1 - right)), (bottom, right, (p0 - top) * (p1 - left)))
+    ref = sum(xp[batch, :, r.long(), c.long()] * wt.abs().view(-1, 1) for r, c, wt in taps)
+    (ref * wi).sum().backward()
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_heuristic_pool_and_eval_mode_calls_are_differentiable():
+    """HeuristicBimodalCSRPool routes the gradient to the selected view rows; an
+    attentive pool in eval mode with autograd on records a graph (BatchNorm on its
+    running statistics) and agrees with the fused inference kernels."""
+    from mvfusion import pooling
+    rng = np.random.default_rng(4)
+    counts = rng.integers(0, 5, 40)
+    ptr = T(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).cuda()
+    V, C = int(ptr[-1]), 6
+    x_mod = T(rng.normal(size=(V, C)).astype(np.float32)).cuda().requires_grad_(True)
+    x_map = T(rng.random((V, 8)).astype(np.float32)).cuda()
+    pool = pooling.HeuristicBimodalCSRPool(mode="max", feat=2)
+    out = pool(None, x_mod, x_map, ptr)
+    w = T(rng.normal(size=out.shape).astype(np.float32)).cuda()
+    (out * w).sum().backward()
+    want = torch.zeros_like(x_mod)
+    for s in range(40):
+        a, b = int(ptr[s]), int(ptr[s + 1])
+        if b > a:
+            want[a + int(torch.argmax(x_map[a:b, 2]))] = w[s]
+    assert torch.equal(x_mod.grad, want)
+
+    torch.manual_seed(0)
+    qkv = pooling.QKVBimodalCSRPool(in_main=5, in_map=8, in_mod=C, out_mod=C, nc_qk=4,
+                                    gating=False).cuda().eval()
+    x_main = T(rng.normal(size=(40, 5)).astype(np.float32)).cuda()
+    xm = x_mod.detach().clone().requires_grad_(True)
+    got = qkv(x_main, xm, x_map, ptr)
+    assert got.requires_grad
+    got.sum().backward()
+    assert xm.grad is not None and float(xm.grad.abs().max()) > 0
+    assert all(p.grad is not None for p in qkv.E_mod.parameters())
+    with torch.no_grad():
+        fused = qkv(x_main, xm, x_map, ptr)
+    assert not fused.requires_grad
+    torch.testing.assert_close(got.detach(), fused, rtol=1e-5, atol=1e-6)
