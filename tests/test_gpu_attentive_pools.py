@@ -2,8 +2,10 @@
 DeepSetFeat, HeuristicBimodalCSRPool) through the C ABI: against the golden
 vectors captured from the reference modules, and against the CPU oracle on
 larger seeded inputs and on the option combinations the fixtures do not cover.
-Tolerance: 1e-5 relative to the output scale (fp32 GEMMs; the summation order
-of the reference's BLAS is not part of its contract)."""
+Tolerance (``_close``): 1e-5 relative, element by element, for every element
+above a tenth of the output's largest magnitude, and 4e-6 of that magnitude for
+every element (fp32 GEMMs; the summation order of the reference's BLAS is not
+part of its contract)."""
 import numpy as np
 import pytest
 import torch
@@ -31,9 +33,27 @@ def _sd(g):
 
 
 def _close(got, want, rtol=1e-5):
+    """Element-wise |got - want| <= rtol * |want| for every element above a tenth
+    of the largest magnitude, and |got - want| <= 0.4 * rtol of the largest
+    magnitude for every element.  The rounding error of a float32 sum scales with
+    the sum of the magnitudes of its terms, not with its result: elements far
+    below the largest are sums that cancel, and no summation order (the
+    reference's BLAS has its own) keeps them to 1e-5 of their own value.
+    Observed over this suite: 5e-6 relative on the large elements, 1e-6 (once
+    3e-6) of the largest magnitude overall.  Returns both observed values."""
     got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64).reshape(got.shape)
     scale = max(float(np.abs(want).max()), 1e-30)
-    np.testing.assert_allclose(got, want.reshape(got.shape), rtol=rtol, atol=rtol * scale)
+    err = np.abs(got - want)
+    big = np.abs(want) > 0.1 * scale
+    worst_rel = float((err[big] / np.abs(want[big])).max()) if big.any() else 0.0
+    worst_abs = float(err.max()) / scale if err.size else 0.0
+    assert worst_rel <= rtol and worst_abs <= 0.4 * rtol, \
+        f"worst relative error {worst_rel:.2e} (limit {rtol:.0e}) on the {int(big.sum())} elements above " \
+        f"a tenth of the largest magnitude; worst error overall {worst_abs:.2e} of that magnitude " \
+        f"(limit {0.4 * rtol:.0e})"
+    return worst_rel, worst_abs
 
 
 @pytest.mark.parametrize("name", ["qkv_default", "qkv_groups4", "qkv_nogate"])

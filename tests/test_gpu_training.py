@@ -2,7 +2,8 @@
 backward through the CSR kernels) against one training step of the reference's
 own modules: output, input gradients, parameter gradients and running
 statistics.  float32 on both sides with different summation orders: compared
-to 2e-4 of the largest magnitude of each tensor."""
+to 1e-5 of the largest magnitude of each tensor (observed: at most 1.6e-6, on
+weight gradients, which sum over every row)."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +12,7 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
-def close(got, want, tol=2e-4):
+def close(got, want, tol=1e-5):
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape
     scale = max(np.abs(want).max(), 1e-6)
