@@ -288,6 +288,43 @@ int mvf_map_images_depth(
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * ImageMapping.from_dense (core/multimodal/image.py:1738-1805; lexargsort /
+ * lexargunique, utils/multimodal.py:289-323; CSRData(dense=True) and
+ * insert_empty_groups, core/multimodal/csr.py:54-79,158-172,197-229) in one
+ * launch set: one 64-bit key per row, one stable radix sort, no host sort.
+ * Rows are (point, image, pixel) triples; point_ids / image_ids / features are
+ * given per row, or per source view when row2view [rows] (may be NULL) maps
+ * every row to its view -- the dense expansion of
+ * ImageMapping.select_points(mode='merge') (image.py:2245-2263) without the
+ * repeat_interleave temporaries.  dedupe != 0 drops rows that repeat an
+ * earlier (point, image, x, y) (lexargunique, image.py:2265-2268).
+ * point_ids < num_points, image_ids < num_images, num_points * num_images
+ * < 2^32, pixels non-negative.
+ * Outputs: pointers [num_points + 1]; images, view_pointers (+1), out_pixels,
+ * out_features ([views][F], mean over the view's kept rows in sorted order)
+ * with room for `rows` entries.  counters[0] <- views, [1] <- pixels kept.
+ * Pixels of a view come out in ascending (x, y), views of a point in ascending
+ * image (the reference's order inside a view is unspecified).
+ * ---------------------------------------------------------------------- */
+size_t mvf_mapping_from_dense_workspace_bytes(int64_t rows, int64_t num_points);
+int mvf_mapping_from_dense(
+    const int64_t *point_ids, const int64_t *image_ids, const int32_t *row2view,
+    const int16_t *pixels, const float *features, int32_t F, int64_t rows,
+    int64_t num_points, int64_t num_images, int32_t dedupe, int64_t *pointers,
+    int64_t *images, int64_t *view_pointers, int16_t *out_pixels,
+    float *out_features, int64_t *counters, void *workspace, size_t workspace_bytes,
+    void *stream);
+
+/* out[r] = mean of feats over the rows that share keys[r] (0 <= keys <=
+ * max_key), rows added in input order: the view features of
+ * select_points(mode='merge') averaged over the views that land on the same
+ * (point, image) pair and handed back to each of them (image.py:2229-2243).
+ * Workspace: mvf_mapping_from_dense_workspace_bytes(n, 1). */
+int mvf_group_mean(
+    const int64_t *keys, const float *feats, int32_t F, int64_t n, int64_t max_key,
+    float *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * torch_scatter.segment_csr(src, ptr, reduce) on dim 0 of a [rows][C] float32
  * matrix (modules/multimodal/pooling.py:63 and :289,295,519,525,628,799,819,
  * 863; core/multimodal/image.py:1777).  out: [nseg][C]; empty segment -> 0;

@@ -91,6 +91,10 @@ _SIGNATURES = {
     "mvf_map_images_depth_workspace_bytes": (_SZ, [_I64, _I32]),
     "mvf_map_images_depth": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P, _P,
                                        _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
+    "mvf_mapping_from_dense_workspace_bytes": (_SZ, [_I64, _I64]),
+    "mvf_mapping_from_dense": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _I64, _I64, _I32, _P, _P, _P,
+                                         _P, _P, _P, _P, _SZ, _P]),
+    "mvf_group_mean": (C.c_int, [_P, _P, _I32, _I64, _I64, _P, _P, _SZ, _P]),
     "mvf_segment_csr": (C.c_int, [_P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_csr_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_softmax_csr_backward": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P]),

@@ -59,6 +59,45 @@ def lexunique(col):
     return torch.unique(col, sorted=True)
 
 
+def _csr_from_dense_rows(point_ids, image_ids, pixels, features, num_points, num_images,
+                         dedupe=False, row2view=None):
+    """Nested CSR arrays from dense rows on the device (``mvf_mapping_from_dense``:
+    one key per row, one radix sort).  ``point_ids`` / ``image_ids`` / ``features``
+    are per row, or per source view when ``row2view`` (int32 [rows]) is given.
+    Returns pointers, images, view pointers, pixels, features (or None)."""
+    import ctypes as C  # noqa: F401
+    from . import _lib as L
+    dev = pixels.device
+    lib = L.load()
+    rows = pixels.shape[0]
+    point_ids = point_ids.to(torch.int64).contiguous()
+    image_ids = image_ids.to(torch.int64).contiguous()
+    pixels = pixels.contiguous()
+    F = 0 if features is None else int(features.shape[1])
+    feats = None if features is None else features.to(torch.float32).contiguous()
+    pointers = torch.empty(num_points + 1, dtype=torch.int64, device=dev)
+    images = torch.empty(rows, dtype=torch.int64, device=dev)
+    view_ptr = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+    out_pix = torch.empty((rows, 2), dtype=torch.int16, device=dev)
+    out_feat = torch.empty((rows, F), dtype=torch.float32, device=dev) if F else None
+    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    ws = L.workspace(lib.mvf_mapping_from_dense_workspace_bytes(rows, num_points), dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mvf_mapping_from_dense(
+            L.ptr(point_ids), L.ptr(image_ids), L.ptr(row2view), L.ptr(pixels), L.ptr(feats), F,
+            rows, num_points, num_images, int(bool(dedupe)), L.ptr(pointers), L.ptr(images),
+            L.ptr(view_ptr), L.ptr(out_pix), L.ptr(out_feat), L.ptr(counters), L.ptr(ws),
+            ws.numel(), L.stream_ptr(dev)))
+    n_views, n_pix = counters.tolist()
+    return (pointers, images[:n_views], view_ptr[:n_views + 1], out_pix[:n_pix],
+            out_feat[:n_views] if F else None)
+
+
+def _device_assembly_fits(pixels, rows, num_points, num_images):
+    return (pixels.is_cuda and pixels.dtype == torch.int16 and 0 < rows < 2 ** 32 - 1
+            and num_points * num_images < 2 ** 32)
+
+
 class ImageMapping(CSRData):
 
     @staticmethod
@@ -79,6 +118,17 @@ class ImageMapping(CSRData):
             dev = L.require_device()
             point_ids, image_ids, pixels = point_ids.to(dev), image_ids.to(dev), pixels.to(dev)
             features = features.to(dev) if features is not None else None
+
+        rows = point_ids.shape[0]
+        if rows > 0 and pixels.dtype == torch.int16 and (features is None or features.dim() == 2):
+            # one launch set on the device: key per row, radix sort, CSR assembly
+            p_max, i_max = torch.stack([point_ids.max(), image_ids.max()]).tolist()
+            n_pts = max(int(num_points or 0), int(p_max) + 1)
+            if _device_assembly_fits(pixels, rows, n_pts, int(i_max) + 1):
+                arrays = _csr_from_dense_rows(
+                    point_ids, image_ids, pixels, features, n_pts, int(i_max) + 1)
+                return ImageMapping.from_csr_arrays(
+                    arrays[0], arrays[1], arrays[3], arrays[4], arrays[2]).to(in_device)
 
         order = lexargsort(point_ids, image_ids, pixels[:, 0], pixels[:, 1])
         point_ids, image_ids, pixels = point_ids[order], image_ids[order], pixels[order]
@@ -204,6 +254,12 @@ class ImageMapping(CSRData):
         if not torch.arange(int(idx.max()) + 1, device=self.device).equal(idx.unique()):
             return self.clone()
 
+        n_new = int(idx.max()) + 1
+        n_img = int(self.images.max()) + 1
+        if _device_assembly_fits(self.pixels, self.pixels.shape[0], n_new, n_img) \
+                and self.num_items < 2 ** 31:
+            return self._merge_points_device(idx, n_new, n_img)
+
         # dense view-level format
         view_sizes = self.pointers[1:] - self.pointers[:-1]
         point_ids = idx.repeat_interleave(view_sizes)
@@ -237,7 +293,39 @@ class ImageMapping(CSRData):
         keep = lexargunique(point_ids, image_ids, pixels[:, 0], pixels[:, 1])
         return ImageMapping.from_dense(
             point_ids[keep], image_ids[keep], pixels[keep],
-            features[keep] if features is not None else None, num_points=int(idx.max()) + 1)
+            features[keep] if features is not None else None, num_points=n_new)
+
+    def _merge_points_device(self, idx, n_new, n_img):
+        """select_points(mode='merge') on the device: per view the new point id and
+        the feature mean over the views that land on the same (point, image) pair
+        (``mvf_group_mean``), then one ``mvf_mapping_from_dense`` pass over the
+        pixels, which reads the view-level arrays through the pixels' view index
+        and drops duplicate pixels."""
+        from . import _lib as L
+        from . import dense as _dense
+        dev = self.device
+        lib = L.load()
+        n_views = self.num_items
+        view_point = _dense.csr_row_segments(self.pointers.contiguous(), n_views)       # int32 [Vw]
+        new_point = idx.to(torch.int64)[view_point.long()].contiguous()
+        images = self.images.to(torch.int64).contiguous()
+        feats = None
+        if self.has_features:
+            feats = self.features.to(torch.float32).contiguous()
+            if n_views > 1:
+                keys = (new_point * n_img + images).contiguous()
+                out = torch.empty_like(feats)
+                ws = L.workspace(lib.mvf_mapping_from_dense_workspace_bytes(n_views, 1), dev)
+                with torch.cuda.device(dev):
+                    L.check(lib.mvf_group_mean(
+                        L.ptr(keys), L.ptr(feats), feats.shape[1], n_views, n_new * n_img, L.ptr(out),
+                        L.ptr(ws), ws.numel(), L.stream_ptr(dev)))
+                feats = out
+        view_ptr = self.values[1].pointers.contiguous()
+        row2view = _dense.csr_row_segments(view_ptr, self.pixels.shape[0])
+        arrays = _csr_from_dense_rows(new_point, images, self.pixels, feats, n_new, n_img,
+                                      dedupe=True, row2view=row2view)
+        return ImageMapping.from_csr_arrays(arrays[0], arrays[1], arrays[3], arrays[4], arrays[2])
 
     def rescale_images(self, ratio):
         """Mappings at a new image resolution: downscaled when ``ratio < 1``,

@@ -3,7 +3,9 @@ written to profiles/pmc_traffic.json for bench.py's roofline.traffic field.
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte request
 as 64 bytes for wide streaming reads, so it is doubled (an upper bound for
 narrow reads).
-usage: python profiles/make_traffic.py <cfg> <fetch_dir> <write_dir> [steps_per_run]"""
+usage: python profiles/make_traffic.py <cfg> <fetch_dir> <write_dir> [output.json]
+(default output: profiles/pmc_traffic.json).  "step" = all kernels of one bench step
+(one launch of the first mapping kernel each), "forward" = one QKVBimodalCSRPool forward."""
 import collections
 import csv
 import glob
@@ -13,7 +15,9 @@ import sys
 
 STAGE = {"bin_count_kernel": "bin_count", "tile_scan_kernel": "tile_scan", "bin_fill_kernel": "bin_fill",
          "tile_zbuffer_kernel": "tile_zbuffer", "mi_centre_kernel": "centre",
-         "mi_point_mask_kernel": "point_mask", "mi_fill_kernel": "csr_fill"}
+         "mi_point_mask_kernel": "point_mask", "mi_fill_kernel": "csr_fill",
+         "two_level_pool_kernel": "pools", "ne_scan_kernel": "pixel_scan", "ne_point_kernel": "point_mask",
+         "ne_fill_kernel": "csr_fill"}
 
 
 def per_kernel(d, counter):
@@ -27,6 +31,7 @@ def per_kernel(d, counter):
 
 
 cfg, fdir, wdir = sys.argv[1:4]
+out_path = sys.argv[4] if len(sys.argv) > 4 else None
 fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
 out = {}
 detail = {}
@@ -37,9 +42,13 @@ for k in sorted(set(fetch) | set(write)):
     out[STAGE.get(k, k)] = f + w
 # one QKVBimodalCSRPool.forward = all launches between two score launches
 nfwd = len(fetch.get("attention_scores_kernel", []))
+total = sum(2.0 * sum(fetch[k]) + sum(write[k]) for k in set(fetch) | set(write))
 if nfwd:
-    out["forward"] = sum(2.0 * sum(fetch[k]) + sum(write[k]) for k in set(fetch) | set(write)) / nfwd
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
+    out["forward"] = total / nfwd
+nstep = max(len(fetch.get("bin_count_kernel", [])), len(fetch.get("mi_point_mask_kernel", [])))
+if nstep and not nfwd:
+    out["step"] = total / nstep
+path = out_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 data[cfg] = out
 data[cfg + "_detail"] = detail

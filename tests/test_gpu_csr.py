@@ -394,3 +394,53 @@ def test_crop_image_groups_golden(golden):
     empty = sample()[torch.zeros(0, dtype=torch.long, device=DEV)]
     _, out = CropImageGroups()(Data(), empty)
     assert isinstance(out, ImageData) and len(out) == 1 and out[0].num_views == 0
+
+
+def test_from_dense_and_merge_large_vs_oracle():
+    """The device CSR assembly (one key per row, one radix sort) at a size where
+    the sort runs many blocks: from_dense on 300 k dense rows with repeated rows,
+    unseen points and unseen images, then select_points('merge') that folds the
+    points 5 to 1 (duplicate pixels dropped, view features averaged over the
+    merged views); both against the oracle."""
+    import mvf_oracle as orc
+    rng = np.random.default_rng(12)
+    n_pts, n_img, rows, F = 40_000, 23, 300_000, 3
+    point_ids = rng.integers(0, n_pts - 50, rows)            # the last points stay empty
+    image_ids = rng.integers(0, n_img, rows)
+    pixels = np.stack([rng.integers(0, 40, rows), rng.integers(0, 30, rows)], 1).astype(np.int16)
+    feats = rng.random((rows, F), dtype=np.float32)
+    want = orc.mapping_from_dense(point_ids, image_ids, pixels, feats, num_points=n_pts)
+    m = M.ImageMapping.from_dense(T(point_ids).cuda(), T(image_ids).cuda(), T(pixels).cuda(),
+                                  T(feats).cuda(), num_points=n_pts)
+    assert m.is_cuda if hasattr(m, "is_cuda") else m.pointers.is_cuda
+    assert np.array_equal(N(m.pointers), want["pointers"])
+    assert np.array_equal(N(m.images), want["images"])
+    assert np.array_equal(N(m.atomic_csr_indexing), want["view_pointers"])
+    assert np.array_equal(N(m.pixels), want["pixels"])       # (x, y) order inside a view on both sides
+    np.testing.assert_allclose(N(m.features), want["features"], rtol=1e-6, atol=1e-7)
+
+    idx = np.arange(n_pts) // 5
+    idx = idx[rng.permutation(n_pts)]                        # merge targets in any order
+    assert np.array_equal(np.unique(idx), np.arange(idx.max() + 1))
+    small = 6_000                                            # the oracle's merge loops over groups
+    sub_rows = point_ids < small
+    m_small = M.ImageMapping.from_dense(
+        T(point_ids[sub_rows]).cuda(), T(image_ids[sub_rows]).cuda(), T(pixels[sub_rows]).cuda(),
+        T(feats[sub_rows]).cuda(), num_points=small)
+    ref_small = orc.mapping_from_dense(point_ids[sub_rows], image_ids[sub_rows], pixels[sub_rows],
+                                       feats[sub_rows], num_points=small)
+    idx_small = np.arange(small) // 5
+    idx_small = idx_small[rng.permutation(small)]
+    want_m = orc.select_points(ref_small, idx_small, mode="merge")
+    got_m = m_small.select_points(T(idx_small).cuda(), mode="merge")
+    assert np.array_equal(N(got_m.pointers), want_m["pointers"])
+    assert np.array_equal(N(got_m.images), want_m["images"])
+    assert np.array_equal(N(got_m.atomic_csr_indexing), want_m["view_pointers"])
+    assert np.array_equal(N(got_m.pixels), want_m["pixels"])
+    np.testing.assert_allclose(N(got_m.features), want_m["features"], rtol=1e-6, atol=1e-7)
+    assert want_m["pixels"].shape[0] < ref_small["pixels"].shape[0]        # duplicates were dropped
+    # the full-size merge agrees with the same merge composed from torch sorts
+    got = m.select_points(T(idx).cuda(), mode="merge")
+    assert got.num_groups == idx.max() + 1 and got.pixels.shape[0] < rows
+    vp = N(got.atomic_csr_indexing)
+    assert np.all(np.diff(vp) > 0) and vp[-1] == got.pixels.shape[0]
