@@ -325,6 +325,22 @@ int mvf_group_mean(
     float *out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * Per-image statistics of a mapping in one pass over its views: stats
+ * [n_img][5] = {mapped pixels, x min, x max, y min, y max} of every image
+ * (all zero for an image without pixels).  Replaces the
+ * repeat_interleave + torch_scatter.scatter_min / scatter_max of
+ * ImageMapping.bounding_boxes (core/multimodal/image.py:1869-1879) and the
+ * scatter_add / bounding-box areas of PickImagesFromMappingArea
+ * (core/data_transform/multimodal/image.py:733-752); CropImageGroups
+ * (:1040-1141) sizes its crops from the same boxes.
+ * view_pointers [n_views + 1], images [n_views] (ids outside [0, n_img) are
+ * skipped), pixels [P][2] int16 (pixel_bytes = 2) or int64 (8).
+ * ---------------------------------------------------------------------- */
+int mvf_image_stats(
+    const int64_t *view_pointers, const int64_t *images, const void *pixels,
+    int32_t pixel_bytes, int64_t n_views, int64_t n_img, int64_t *stats, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * torch_scatter.segment_csr(src, ptr, reduce) on dim 0 of a [rows][C] float32
  * matrix (modules/multimodal/pooling.py:63 and :289,295,519,525,628,799,819,
  * 863; core/multimodal/image.py:1777).  out: [nseg][C]; empty segment -> 0;

@@ -133,6 +133,80 @@ __global__ __launch_bounds__(256) void gm_mean_kernel(
     for (i64 u = s; u < t; ++u) out[(size_t)vals[u] * F + c] = mean;
 }
 
+// ---- per-image statistics of a mapping: pixel count and bounding box --------
+// stats[i] = {pixels, x min, x max, y min, y max} of image i.  A block walks a
+// contiguous chunk of views and keeps the partial results of up to IS_SLOTS
+// images in LDS, so that the global atomics are one set per (block, image)
+// instead of one per view.
+constexpr int IS_SLOTS = 1024;
+constexpr int IS_VIEWS_PER_BLOCK = 256 * 16;
+constexpr i64 IS_MAX = 0x7fffffffffffffffll, IS_MIN = -IS_MAX - 1;
+
+__global__ __launch_bounds__(256) void image_stats_init_kernel(i64 *__restrict__ stats, i64 n_img)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_img * 5) return;
+    const int c = (int)(i % 5);
+    stats[i] = c == 0 ? 0 : ((c & 1) ? IS_MAX : IS_MIN);
+}
+
+__device__ __forceinline__ void image_stats_merge(i64 *slot, i64 n, i64 x0, i64 x1, i64 y0, i64 y1)
+{
+    atomicAdd((unsigned long long *)slot, (unsigned long long)n);
+    atomicMin((long long *)slot + 1, (long long)x0);
+    atomicMax((long long *)slot + 2, (long long)x1);
+    atomicMin((long long *)slot + 3, (long long)y0);
+    atomicMax((long long *)slot + 4, (long long)y1);
+}
+
+template <typename PIX>
+__global__ __launch_bounds__(256) void image_stats_kernel(
+    const i64 *__restrict__ view_ptr, const i64 *__restrict__ images, const PIX *__restrict__ pixels,
+    i64 n_views, i64 n_img, i64 *__restrict__ stats)
+{
+    __shared__ i64 part[IS_SLOTS * 5];
+    const bool staged = n_img <= IS_SLOTS;
+    if (staged) {
+        for (int i = threadIdx.x; i < (int)n_img * 5; i += 256) {
+            const int c = i % 5;
+            part[i] = c == 0 ? 0 : ((c & 1) ? IS_MAX : IS_MIN);
+        }
+        __syncthreads();
+    }
+    const i64 first = (i64)blockIdx.x * IS_VIEWS_PER_BLOCK;
+    const i64 last = first + IS_VIEWS_PER_BLOCK < n_views ? first + IS_VIEWS_PER_BLOCK : n_views;
+    for (i64 v = first + threadIdx.x; v < last; v += 256) {
+        const i64 b = view_ptr[v], e = view_ptr[v + 1];
+        const i64 img = images[v];
+        if (e <= b || img < 0 || img >= n_img) continue;
+        i64 x0 = IS_MAX, x1 = IS_MIN, y0 = IS_MAX, y1 = IS_MIN;
+        for (i64 p = b; p < e; ++p) {
+            const i64 x = (i64)pixels[2 * p], y = (i64)pixels[2 * p + 1];
+            x0 = x < x0 ? x : x0;
+            x1 = x > x1 ? x : x1;
+            y0 = y < y0 ? y : y0;
+            y1 = y > y1 ? y : y1;
+        }
+        image_stats_merge(staged ? part + img * 5 : stats + img * 5, e - b, x0, x1, y0, y1);
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < (int)n_img; i += 256) {
+        const i64 *q = part + i * 5;
+        if (q[0] > 0) image_stats_merge(stats + (i64)i * 5, q[0], q[1], q[2], q[3], q[4]);
+    }
+}
+
+// Images without a pixel report an all-zero row.
+__global__ __launch_bounds__(256) void image_stats_finish_kernel(i64 *__restrict__ stats, i64 n_img)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_img) return;
+    if (stats[i * 5] == 0) {
+        for (int c = 1; c < 5; ++c) stats[i * 5 + c] = 0;
+    }
+}
+
 static int sort_bits(u64 max_value)
 {
     int b = 1;
@@ -250,6 +324,34 @@ extern "C" int mvf_group_mean(
                                       (unsigned)sort_bits((u64)max_key), st));
     hipLaunchKernelGGL(gm_mean_kernel, dim3(cdiv(n * F, 256)), dim3(256), 0, st, ws.keys_b, ws.vals_b, (i64)n,
                        feats, F, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_image_stats(
+    const int64_t *view_pointers, const int64_t *images, const void *pixels, int32_t pixel_bytes,
+    int64_t n_views, int64_t n_img, int64_t *stats, void *stream)
+{
+    MVF_REQUIRE(n_views >= 0 && n_img >= 0, "image_stats: bad sizes");
+    MVF_REQUIRE(pixel_bytes == 2 || pixel_bytes == 8, "image_stats: pixels must be int16 or int64 (got %d bytes)",
+                pixel_bytes);
+    if (n_img == 0) return MVF_OK;
+    MVF_REQUIRE(stats, "image_stats: null output");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 block(256);
+    hipLaunchKernelGGL(image_stats_init_kernel, dim3(cdiv(n_img * 5, 256)), block, 0, st, (i64 *)stats, (i64)n_img);
+    if (n_views > 0) {
+        MVF_REQUIRE(view_pointers && images && pixels, "image_stats: null buffer");
+        const dim3 grid(cdiv(n_views, IS_VIEWS_PER_BLOCK));
+        if (pixel_bytes == 2)
+            hipLaunchKernelGGL(image_stats_kernel<int16_t>, grid, block, 0, st, (const i64 *)view_pointers,
+                               (const i64 *)images, (const int16_t *)pixels, (i64)n_views, (i64)n_img,
+                               (i64 *)stats);
+        else
+            hipLaunchKernelGGL(image_stats_kernel<i64>, grid, block, 0, st, (const i64 *)view_pointers,
+                               (const i64 *)images, (const i64 *)pixels, (i64)n_views, (i64)n_img, (i64 *)stats);
+    }
+    hipLaunchKernelGGL(image_stats_finish_kernel, dim3(cdiv(n_img, 256)), block, 0, st, (i64 *)stats, (i64)n_img);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -95,6 +95,7 @@ _SIGNATURES = {
     "mvf_mapping_from_dense": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _I64, _I64, _I32, _P, _P, _P,
                                          _P, _P, _P, _P, _SZ, _P]),
     "mvf_group_mean": (C.c_int, [_P, _P, _I32, _I64, _I64, _P, _P, _SZ, _P]),
+    "mvf_image_stats": (C.c_int, [_P, _P, _P, _I32, _I64, _I64, _P, _P]),
     "mvf_segment_csr": (C.c_int, [_P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_csr_backward": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_segment_softmax_csr_backward": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P]),

@@ -394,9 +394,15 @@ class ImageMapping(CSRData):
             self.pointers[1:] - self.pointers[:-1]).repeat_interleave(sizes)
         features = self.features.repeat_interleave(sizes, dim=0)[inside] \
             if self.has_features else None
+        kept = pixels[inside]
+        if kept.is_cuda and max(crop_size) < 2 ** 15 and kept.dtype != torch.int16:
+            # the kept pixels lie inside the box: 16 bits hold them, which is what
+            # the device CSR assembly sorts on
+            out = ImageMapping.from_dense(point_ids[inside], image_ids[inside], kept.to(torch.int16),
+                                          features, num_points=self.num_groups)
+            return out._with_pixels(out.pixels.to(kept.dtype))
         return ImageMapping.from_dense(
-            point_ids[inside], image_ids[inside], pixels[inside], features,
-            num_points=self.num_groups)
+            point_ids[inside], image_ids[inside], kept, features, num_points=self.num_groups)
 
     def debug(self):
         super(ImageMapping, self).debug()
@@ -446,6 +452,39 @@ class ImageMapping(CSRData):
     def get_batch_type():
         return ImageMappingBatch
 
+    def image_stats(self, num_images=None):
+        """int64 [num_images, 5]: mapped pixels, x min, x max, y min, y max of
+        every image id (zeros for an image without pixels).  ``num_images``
+        defaults to the largest id present + 1.  On a HIP device this is one
+        pass over the views (``mvf_image_stats``); on the host a scatter
+        composition of the same reductions."""
+        if num_images is None:
+            num_images = int(self.images.max()) + 1 if self.images.numel() else 0
+        view_ptr, pix = self.values[1].pointers, self.pixels
+        stats = torch.zeros((num_images, 5), dtype=torch.int64, device=self.device)
+        if num_images == 0 or self.images.numel() == 0:
+            return stats
+        if pix.is_cuda and pix.dtype in (torch.int16, torch.int64):
+            from . import _lib as L
+            pix = pix.contiguous()
+            with torch.cuda.device(self.device):
+                L.check(L.load().mvf_image_stats(
+                    L.ptr(view_ptr.contiguous()), L.ptr(self.images.contiguous()), L.ptr(pix),
+                    pix.element_size(), self.images.shape[0], num_images, L.ptr(stats),
+                    L.stream_ptr(self.device)))
+            return stats
+        ids = self.images.repeat_interleave(view_ptr[1:] - view_ptr[:-1])
+        keep = (ids >= 0) & (ids < num_images)
+        ids, pix = ids[keep], pix[keep].long()
+        stats[:, 0].index_add_(0, ids, torch.ones_like(ids))
+        idx2 = ids[:, None].expand(-1, 2)
+        lo = torch.zeros((num_images, 2), dtype=torch.int64, device=self.device).scatter_reduce_(
+            0, idx2, pix, 'amin', include_self=False)
+        hi = torch.zeros((num_images, 2), dtype=torch.int64, device=self.device).scatter_reduce_(
+            0, idx2, pix, 'amax', include_self=False)
+        stats[:, 1], stats[:, 2], stats[:, 3], stats[:, 4] = lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1]
+        return stats
+
     @property
     def bounding_boxes(self):
         """(w_min, w_max, h_min, h_max) of the mapped pixels of every image, one
@@ -453,16 +492,8 @@ class ImageMapping(CSRData):
         mappings gets zeros (core/multimodal/image.py:1869-1879, whose
         torch_scatter reductions size their output by the largest index and fill
         empty slots with 0)."""
-        sizes = self.values[1].pointers[1:] - self.values[1].pointers[:-1]
-        image_ids = self.images.repeat_interleave(sizes)
-        n_img = int(image_ids.max()) + 1 if image_ids.numel() else 0
-        pix = self.pixels
-        idx2 = image_ids[:, None].expand(-1, 2)
-        lo = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
-            0, idx2, pix, 'amin', include_self=False)
-        hi = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
-            0, idx2, pix, 'amax', include_self=False)
-        return lo[:, 0], hi[:, 0], lo[:, 1], hi[:, 1]
+        stats = self.image_stats().to(self.pixels.dtype)
+        return stats[:, 1], stats[:, 2], stats[:, 3], stats[:, 4]
 
     @property
     def feature_map_indexing(self):

@@ -874,28 +874,18 @@ class PickImagesFromMappingArea(ImageTransform):
 
     def _process(self, data, images):
         assert images.mappings is not None, "No mappings found in images."
-        m = images.mappings
-        threshold = images.img_size[0] * images.img_size[1] * self.area_ratio
-        sizes = m.values[1].pointers[1:] - m.values[1].pointers[:-1]
-        pixel_idx = m.images.repeat_interleave(sizes)
-        n_img = int(pixel_idx.max()) + 1 if pixel_idx.numel() else 0
-        if not self.use_bbox:
-            areas = torch.zeros(n_img, device=pixel_idx.device).index_add_(
-                0, pixel_idx, torch.ones(pixel_idx.shape[0], device=pixel_idx.device))
+        # one reduction over the views gives every image's pixel count and box
+        stats = images.mappings.image_stats(images.num_views)
+        if self.use_bbox:
+            areas = (stats[:, 2] - stats[:, 1]) * (stats[:, 4] - stats[:, 3])
         else:
-            pix = m.pixels.int()
-            idx2 = pixel_idx[:, None].expand(-1, 2)
-            xy_min = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
-                0, idx2, pix, 'amin', include_self=False)
-            xy_max = torch.zeros((n_img, 2), dtype=pix.dtype, device=pix.device).scatter_reduce_(
-                0, idx2, pix, 'amax', include_self=False)
-            areas = (xy_max[:, 0] - xy_min[:, 0]) * (xy_max[:, 1] - xy_min[:, 1])
-        n_max = images.num_views if self.n_max is None else self.n_max
-        idx = areas.argsort().flip(0)
-        idx = idx[areas[idx] > threshold][:n_max]
-        if idx.shape[0] == 0 and images.num_views > 0 and self.n_min > 0:
-            idx = idx[:self.n_min]
-        return data, images[idx]
+            areas = stats[:, 0]
+        threshold = images.img_size[0] * images.img_size[1] * self.area_ratio
+        ranked = areas.argsort(stable=True).flip(0)
+        ranked = ranked[areas[ranked] > threshold]
+        if self.n_max is not None:
+            ranked = ranked[:self.n_max]
+        return data, images[ranked]
 
 
 class PickMappingsFromMappingFeatures(ImageTransform):
@@ -972,45 +962,52 @@ class CropImageGroups(ImageTransform):
         self.padding = padding
         self.min_size = min_size
 
+    def crop_sizes(self, img_size):
+        """The family of crop sizes, smallest first, ending with the full image:
+        starting from a square of min_size the width and the height double in
+        turn, each capped by the image."""
+        W, H = img_size
+        if self.min_size > W or self.min_size > H:
+            return [(W, H)]
+        sizes, w, h, widen = [], self.min_size, self.min_size, True
+        while (w, h) != (W, H):
+            sizes.append((w, h))
+            w, h = (min(2 * w, W), h) if widen else (w, min(2 * h, H))
+            widen = not widen
+        sizes.append((W, H))
+        return sizes
+
     def _process(self, data, images):
         from .images import ImageData
         assert images.mappings is not None, "No mappings found in images."
         if images.num_views == 0:
             return data, ImageData([images])
-        img_size = tuple(images.img_size)
-        w_min, w_max, h_min, h_max = images.mappings.bounding_boxes
-        w_min = torch.clamp(w_min - self.padding, 0)
-        h_min = torch.clamp(h_min - self.padding, 0)
-        w_max = torch.clamp(w_max + self.padding, 0, img_size[0])
-        h_max = torch.clamp(h_max + self.padding, 0, img_size[1])
-        widths, heights = w_max - w_min, h_max - h_min
+        W, H = (int(v) for v in images.img_size)
+        dev = images.mappings.device
+        pix_dtype = images.mappings.pixels.dtype
+        box = images.mappings.image_stats(images.num_views)[:, 1:].to(pix_dtype)
+        x_lo = (box[:, 0] - self.padding).clamp(min=0)
+        x_hi = (box[:, 1] + self.padding).clamp(0, W)
+        y_lo = (box[:, 2] - self.padding).clamp(min=0)
+        y_hi = (box[:, 3] + self.padding).clamp(0, H)
+        width, height = x_hi - x_lo, y_hi - y_lo
 
-        families = {}
-        size = (self.min_size, self.min_size)
-        step = 0
-        image_ids = torch.arange(images.num_views, device=widths.device)
-        while all(a <= b for a, b in zip(size, img_size)) and image_ids.shape[0] > 0:
-            if size == img_size:
-                families[size] = image_ids
-                image_ids = image_ids[:0]
-                break
-            fits = torch.logical_and(widths[image_ids] <= size[0], heights[image_ids] <= size[1])
-            if bool(fits.any()):
-                families[size] = image_ids[fits]
-            image_ids = image_ids[~fits]
-            # widths double on even steps, heights on odd ones
-            size = (min(size[0] * 2 ** ((step + 1) % 2), img_size[0]),
-                    min(size[1] * 2 ** (step % 2), img_size[1]))
-            step += 1
-        if img_size not in families and image_ids.shape[0] > 0:
-            families[img_size] = image_ids
+        # every image takes the first size of the family that holds its box: one
+        # comparison against the whole family instead of a loop over the sizes
+        sizes = torch.tensor(self.crop_sizes((W, H)), dtype=torch.int64, device=dev)
+        holds = (width[:, None] <= sizes[None, :, 0]) & (height[:, None] <= sizes[None, :, 1])
+        holds[:, -1] = True
+        family = holds.to(torch.uint8).argmax(dim=1)
+        crop_w, crop_h = sizes[family, 0], sizes[family, 1]
+        # the box centred in its crop, as far as the image borders allow
+        off_x = torch.minimum((x_lo - (crop_w - width) / 2.).long().clamp(min=0), W - crop_w)
+        off_y = torch.minimum((y_lo - (crop_h - height) / 2.).long().clamp(min=0), H - crop_h)
+        offsets = torch.stack((off_x, off_y), dim=1)
 
+        family = family.cpu()
         out = []
-        for size, idx in families.items():
-            off_x = torch.clamp((w_min[idx] - (size[0] - widths[idx]) / 2.).long(),
-                                0, img_size[0] - size[0])
-            off_y = torch.clamp((h_min[idx] - (size[1] - heights[idx]) / 2.).long(),
-                                0, img_size[1] - size[1])
-            offsets = torch.stack((off_x, off_y), dim=1).long()
-            out.append(images[idx].update_cropping(size, offsets))
+        for k in family.unique().tolist():
+            idx = torch.where(family == k)[0].to(dev)
+            size = tuple(int(v) for v in sizes[k].tolist())
+            out.append(images[idx].update_cropping(size, offsets[idx]))
         return data, ImageData(out)

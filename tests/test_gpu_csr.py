@@ -444,3 +444,31 @@ def test_from_dense_and_merge_large_vs_oracle():
     assert got.num_groups == idx.max() + 1 and got.pixels.shape[0] < rows
     vp = N(got.atomic_csr_indexing)
     assert np.all(np.diff(vp) > 0) and vp[-1] == got.pixels.shape[0]
+
+
+@pytest.mark.parametrize("n_img,dtype", [(37, np.int16), (1500, np.int64)])
+def test_image_stats_large(n_img, dtype):
+    """Pixel count and bounding box per image in one pass over the views:
+    few images (partial results staged in LDS) and more images than the
+    staging holds (direct atomics), int16 and int64 pixels with negative
+    coordinates, empty views, images without pixels."""
+    rng = np.random.default_rng(n_img)
+    n_views = 200_000
+    sizes = rng.integers(0, 5, n_views)
+    vp = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    images = rng.integers(0, n_img - 3, n_views).astype(np.int64)      # the last ids stay empty
+    pix = rng.integers(-300, 3000, (int(vp[-1]), 2)).astype(dtype)
+    m = M.ImageMapping.from_csr_arrays(
+        T(np.arange(n_views + 1, dtype=np.int64)), T(images), T(pix), None, view_pointers=T(vp))
+    got = m.image_stats(n_img).cpu().numpy()
+    ids = np.repeat(images, sizes)
+    want = np.zeros((n_img, 5), np.int64)
+    np.add.at(want[:, 0], ids, 1)
+    for col, fn, src in ((1, np.minimum, 0), (2, np.maximum, 0), (3, np.minimum, 1), (4, np.maximum, 1)):
+        acc = np.full(n_img, np.iinfo(np.int64).max if fn is np.minimum else np.iinfo(np.int64).min)
+        fn.at(acc, ids, pix[:, src].astype(np.int64))
+        want[:, col] = np.where(want[:, 0] > 0, acc, 0)
+    assert np.array_equal(got, want)
+    boxes = m.bounding_boxes
+    assert boxes[0].dtype == m.pixels.dtype and boxes[0].shape[0] == int(images.max()) + 1
+    assert np.array_equal(boxes[1].cpu().numpy(), want[:int(images.max()) + 1, 2].astype(dtype))

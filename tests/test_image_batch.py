@@ -1,13 +1,33 @@
 """Collation of images and mappings into per-GPU batches, and the view / image
 selections of ImageMapping, against outputs of the reference's own classes
-(fixture image_batch.npz).  Host logic on index tensors: runs without a GPU."""
+(fixture image_batch.npz).  Every case runs on host tensors (index logic, no
+GPU needed) and, marked ``gpu``, on device tensors, where the per-image
+reductions and the CSR re-assembly are HIP kernels."""
 import numpy as np
+import pytest
 import torch
 
 from mvfusion.images import ImageBatch, ImageData, SameSettingImageBatch, SameSettingImageData
 from mvfusion.mapping import ImageMapping, ImageMappingBatch
 
-T = torch.from_numpy
+DEV = "cpu"
+
+
+@pytest.fixture(autouse=True, params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def dev(request):
+    """Device of the tensors the helpers below create."""
+    global DEV
+    DEV = request.param
+    yield request.param
+    DEV = "cpu"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def N(t):
+    return t.cpu().numpy()
 
 
 def mapping(g, prefix):
@@ -17,11 +37,12 @@ def mapping(g, prefix):
 
 
 def same(m, g, prefix):
-    assert np.array_equal(m.pointers.numpy(), g[prefix + "pointers"]), prefix
-    assert np.array_equal(m.images.numpy(), g[prefix + "images"]), prefix
-    assert np.array_equal(m.values[1].pointers.numpy(), g[prefix + "view_pointers"]), prefix
-    assert np.array_equal(m.pixels.numpy(), g[prefix + "pixels"]), prefix
-    assert np.array_equal(m.features.numpy(), g[prefix + "features"]), prefix
+    assert m.device.type == DEV
+    assert np.array_equal(N(m.pointers), g[prefix + "pointers"]), prefix
+    assert np.array_equal(N(m.images), g[prefix + "images"]), prefix
+    assert np.array_equal(N(m.values[1].pointers), g[prefix + "view_pointers"]), prefix
+    assert np.array_equal(N(m.pixels), g[prefix + "pixels"]), prefix
+    assert np.array_equal(N(m.features), g[prefix + "features"]), prefix
 
 
 def items(g, tag, size):
@@ -31,8 +52,9 @@ def items(g, tag, size):
         n = g[p + "pos"].shape[0]
         out.append(SameSettingImageData(
             path=[f"{tag}{i}_{k}" for k in range(n)], pos=T(g[p + "pos"]),
-            extrinsic=torch.eye(4).repeat(n, 1, 1), fx=torch.ones(n), fy=torch.ones(n),
-            mx=torch.zeros(n), my=torch.zeros(n), ref_size=(size, size), proj_upscale=1,
+            extrinsic=torch.eye(4, device=DEV).repeat(n, 1, 1), fx=torch.ones(n, device=DEV),
+            fy=torch.ones(n, device=DEV),
+            mx=torch.zeros(n, device=DEV), my=torch.zeros(n, device=DEV), ref_size=(size, size), proj_upscale=1,
             downscale=1, x=T(g[p + "x"]), mappings=mapping(g, p)))
     return out
 
@@ -43,14 +65,14 @@ def test_same_setting_image_batch(golden):
     b = SameSettingImageBatch.from_data_list(big)
     assert isinstance(b.mappings, ImageMappingBatch)
     same(b.mappings, g, "ssb_")
-    assert np.array_equal(b.pos.numpy(), g["ssb_pos"])
-    assert np.array_equal(b.x.numpy(), g["ssb_x"])
+    assert np.array_equal(N(b.pos), g["ssb_pos"])
+    assert np.array_equal(N(b.x), g["ssb_x"])
     assert np.array_equal(b.batch_items_sizes, g["ssb_sizes"])
     assert b.num_views == sum(im.num_views for im in big) and b.num_batch_items == 3
     back = b.to_data_list()
     assert [im.num_views for im in back] == [im.num_views for im in big]
     same(back[1].mappings, g, "ssb_item1_")
-    assert np.array_equal(back[1].pos.numpy(), big[1].pos.numpy())
+    assert np.array_equal(N(back[1].pos), N(big[1].pos))
     assert torch.equal(back[2].x, big[2].x)
     # different settings cannot be batched together
     small = items(g, "small", 32)
@@ -67,12 +89,12 @@ def test_select_images_and_views(golden):
     same(m.select_images(T(g["sel_idx"])), g, "sel_")
     out, img_idx = m.select_views(T(g["view_mask"]))
     same(out, g, "views_")
-    assert np.array_equal(img_idx.numpy(), g["views_img_idx"])
+    assert np.array_equal(N(img_idx), g["views_img_idx"])
     # all views kept: nothing to renumber
-    out, img_idx = m.select_views(torch.ones(m.num_items, dtype=torch.bool))
+    out, img_idx = m.select_views(torch.ones(m.num_items, dtype=torch.bool, device=DEV))
     assert img_idx is None and torch.equal(out.pointers, m.pointers)
     # no image kept: every point becomes empty
-    empty = m.select_images(torch.zeros(0, dtype=torch.int64))
+    empty = m.select_images(torch.zeros(0, dtype=torch.int64, device=DEV))
     assert empty.num_items == 0 and int(empty.pointers.max()) == 0
     # selecting views of a SameSettingImageData re-indexes its mappings too
     im = items(g, "big", 64)[1][T(g["sel_idx"])]
@@ -90,7 +112,7 @@ def test_image_batch(golden):
     for ssb in ib:
         k = by_size[ssb.ref_size[0]]
         same(ssb.mappings, g, f"ib{k}_")
-        assert np.array_equal(ssb.pos.numpy(), g[f"ib{k}_pos"])
+        assert np.array_equal(N(ssb.pos), g[f"ib{k}_pos"])
         assert ssb.mappings.num_groups == n_total
     back = ib.to_data_list()
     for i, il in enumerate(back):
@@ -118,7 +140,7 @@ def _sample(g):
 
 
 def _same_images(im, g, tag):
-    assert np.array_equal(im.pos.numpy(), g[tag + "_pos"]), tag
+    assert np.array_equal(N(im.pos), g[tag + "_pos"]), tag
     assert [str(p) for p in im.path] == [str(p) for p in g[tag + "_path"]], tag
     same(im.mappings, g, tag + "_")
 
@@ -132,7 +154,7 @@ def test_select_points_and_views_on_images(golden):
     _same_images(_sample(g).select_points(T(g["pick"]), mode="pick"), g, "pick")
     _same_images(_sample(g).select_views(T(g["view_mask"])), g, "views")
     im = _sample(g)
-    assert im.select_views(torch.ones(im.mappings.num_items, dtype=torch.bool)).num_views == im.num_views
+    assert im.select_views(torch.ones(im.mappings.num_items, dtype=torch.bool, device=DEV)).num_views == im.num_views
     both = ImageData([_sample(g), _sample(g)]).select_points(T(g["pick"]), mode="pick")
     assert len(both) == 2
     _same_images(both[1], g, "pick")
@@ -146,9 +168,9 @@ def test_image_selection_transforms(golden):
     sub = g["sub"]
     data = _Data(pos=T(g["xyz"][sub]), mapping_index=T(sub))
     d2, out = SelectMappingFromPointId()(data, _sample(g))
-    assert np.array_equal(d2.mapping_index.numpy(), g["smfp_index"])
+    assert np.array_equal(N(d2.mapping_index), g["smfp_index"])
     _same_images(out, g, "smfp")
-    data = _Data(pos=T(g["xyz"]), mapping_index=torch.arange(n))
+    data = _Data(pos=T(g["xyz"]), mapping_index=torch.arange(n, device=DEV))
     _, out = DropImagesOutsideDataBoundingBox(margin=0.5)(data, _sample(g))
     _same_images(out, g, "bbox")
     _, out = PickImagesFromMappingArea(area_ratio=0.02, n_max=3)(data, _sample(g))
@@ -162,7 +184,7 @@ def test_image_selection_transforms(golden):
 # ------------------------------------------------------------- crop groups
 def _crop_sample(g):
     n_img, (W, H) = int(g["n_img"]), (int(v) for v in g["size"])
-    x = torch.arange(n_img * 2 * H * W, dtype=torch.float32).view(n_img, 2, H, W)
+    x = torch.arange(n_img * 2 * H * W, dtype=torch.float32, device=DEV).view(n_img, 2, H, W)
     return SameSettingImageData(
         path=[f"v{i}" for i in range(n_img)], pos=T(g["pos_img"]), ref_size=(W, H),
         proj_upscale=1, downscale=1, mappings=mapping(g, "in_"), x=x)
@@ -176,8 +198,8 @@ def test_bounding_boxes_and_feature_thresholds(golden):
     g = golden("crop_groups")
     boxes = _crop_sample(g).mappings.bounding_boxes
     for k, v in zip(("w_min", "w_max", "h_min", "h_max"), boxes):
-        assert np.array_equal(v.numpy(), g["bbox_" + k]) and v.numpy().dtype == g["bbox_" + k].dtype
-    data = _Data(pos=torch.zeros(3, 3))
+        assert np.array_equal(N(v), g["bbox_" + k]) and N(v).dtype == g["bbox_" + k].dtype
+    data = _Data(pos=torch.zeros(3, 3, device=DEV))
     _, out = PickMappingsFromMappingFeatures(feat=[0, 2], lower=[0.2, None], upper=[None, 0.7])(
         data, _crop_sample(g))
     assert [str(p) for p in out.path] == [str(p) for p in g["pmf_path"]]
