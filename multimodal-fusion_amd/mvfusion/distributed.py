@@ -31,10 +31,13 @@ def my_samples(sizes, rank=None, world_size=None):
     return partition_samples(sizes, world_size)[rank]
 
 
-def gather_rows(t, group=None):
+def gather_rows(t, group=None, max_padding=1.25):
     """All-gather of per-rank row blocks of different length: [n_r, ...] on
     rank r -> [sum n_r, ...] on every rank, rank-major.  One small all-gather
-    of the counts, then one padded all-gather of the payload."""
+    of the counts, then the payload: one all-gather of blocks padded to the
+    longest when that moves at most ``max_padding`` times the rows there are
+    (balanced shards), otherwise one broadcast per rank straight into its slice
+    of the result, so that an uneven partition does not travel as padding."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t, [t.shape[0]]
@@ -43,13 +46,26 @@ def gather_rows(t, group=None):
     counts = torch.empty(world, dtype=torch.int64, device=t.device)
     dist.all_gather_into_tensor(counts, n, group=group)
     counts = counts.tolist()
-    cap = max(counts)
-    pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[:t.shape[0]] = t
-    out = torch.empty((world * cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-    out = out.view((world, cap) + tuple(t.shape[1:]))
-    return torch.cat([out[r, :counts[r]] for r in range(world)], dim=0), counts
+    cap, total = max(counts), sum(counts)
+    tail = tuple(t.shape[1:])
+    if world * cap <= max_padding * total:
+        pad = torch.zeros((cap,) + tail, dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        out = torch.empty((world * cap,) + tail, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
+        out = out.view((world, cap) + tail)
+        return torch.cat([out[r, :counts[r]] for r in range(world)], dim=0), counts
+    out = torch.empty((total,) + tail, dtype=t.dtype, device=t.device)
+    me, start = dist.get_rank(group), 0
+    for r in range(world):
+        block = out[start:start + counts[r]]
+        if r == me:
+            block.copy_(t)
+        if counts[r]:
+            dist.broadcast(block, src=dist.get_global_rank(group, r) if group is not None else r,
+                           group=group)
+        start += counts[r]
+    return out, counts
 
 
 def gather_pooled(features, labels=None, group=None):

@@ -567,6 +567,24 @@ class MapImages(ImageTransform):
             pass
         return staged
 
+    @staticmethod
+    def _stage_views(images, camera, device):
+        """The packed views on the device, kept on ``images`` for the next call on
+        the same, unmodified camera tensors."""
+        src = [images.pos, images.extrinsic, images.crop_offsets] + [
+            getattr(images, k) for k in ('fx', 'fy', 'mx', 'my')]
+        key = (str(device), camera) + tuple(
+            (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else repr(t) for t in src)
+        cached = getattr(images, '_mvf_views', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        views = pack_views(images, camera).to(device)
+        try:
+            images._mvf_views = (key, views)
+        except Exception:
+            pass
+        return views
+
     def prepare_fused(self, data, images, visi_model, device):
         """Stage one sample on the device for the fused path: points permuted
         into the sampler's order, mapping ids and their inverse, packed views.
@@ -582,8 +600,7 @@ class MapImages(ImageTransform):
             return None
         pos, ids, inv, attrs, num_points = staged
         return FusedMapPlan(
-            pos, ids, inv, attrs,
-            pack_views(images, visi_model.camera).to(device),
+            pos, ids, inv, attrs, self._stage_views(images, visi_model.camera, device),
             images.mask.to(device=device, dtype=torch.uint8).contiguous()
             if images.mask is not None else None,
             visibility_module.make_params(**visi_model.__dict__), bool(self.cylinder),
@@ -609,7 +626,10 @@ class MapImages(ImageTransform):
         if img_ids.shape[0] == 0:
             raise ValueError(_NO_MAPPING_MSG)
         mappings = ImageMapping.from_csr_arrays(pointers, img_ids, pixels, feats, *res[5:])
-        seen = torch.where(view_seen > 0)[0]
+        if plan.last_counts['seen_views'] == images.num_views:
+            seen = torch.arange(images.num_views)          # every view kept: nothing to look up
+        else:
+            seen = torch.where(view_seen > 0)[0]
         self.timings['t_stage'] = (t1 - t0) * 1e3 - self.timings['t_sphere_sampling']
         self.timings['t_visibility'] = (t2 - t1) * 1e3
         self.timings['t_ImageMapping_init'] = (time.perf_counter() - t2) * 1e3

@@ -46,6 +46,16 @@ def _worker(rank, world, port, q):
         labels = torch.cat([torch.full((sizes[i],), i, dtype=torch.int64) for i in mine]) \
             if mine else torch.zeros(0, dtype=torch.int64)
         f, l, counts = D.gather_pooled(feats, labels)
+        # uneven blocks (20 rows against 1, then against none): travel as one
+        # broadcast per rank instead of blocks padded to the longest
+        for n_other in (1, 0):
+            mine_rows = 20 if rank == 0 else n_other
+            t = torch.arange(mine_rows * 3, dtype=torch.float32).view(mine_rows, 3) + 1000 * rank
+            u, c = D.gather_rows(t)
+            assert c == [20, n_other] and u.shape == (20 + n_other, 3)
+            assert torch.equal(u[:20], torch.arange(60, dtype=torch.float32).view(20, 3))
+            if n_other:
+                assert torch.equal(u[20:], torch.arange(3, dtype=torch.float32).view(1, 3) + 1000)
         q.put((rank, mine, f.numpy(), l.numpy(), counts))
     finally:
         dist.destroy_process_group()
