@@ -359,6 +359,17 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     N, V = plan.N, plan.V
     W, H = sc["img_size"]
     N_all = sum(p.N for _, p in staged)
+    # A batch of samples goes through one launch set (mvf_map_images_exact_batch: every
+    # point faces the views of its own sample, the output is the collated batch);
+    # --batched 0 maps the samples one by one and collates them with torch.
+    batched = n_samples > 1 and exact and not depth and bool(getattr(args, "batched", 1))
+    if batched:
+        from mvfusion.transforms import FusedMapPlan
+        plan = FusedMapPlan.batched([p for _, p in staged])
+        staged = [(sc, plan)]
+        unit = 1                       # samples per plan run: the whole batch is one pass
+    else:
+        unit = n_samples
     gen = torch.Generator(device=device).manual_seed(rank)
     labels = torch.randint(0, 19, (N_all,), device=device, generator=gen)
     # pixel features for every possible mapping row, resident in HBM
@@ -391,7 +402,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     # round trip.
     n_lanes = max(1, args.lanes)
     streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
-    if n_samples == 1:
+    if unit == 1:
         plans = [plan] + [plan.twin(k) for k in range(1, n_lanes)]
     else:
         plans = [p for _, p in staged]
@@ -463,7 +474,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             cur.wait_stream(s)
         return out
 
-    run_steps = run_steps_single if n_samples == 1 else run_steps_batch
+    run_steps = run_steps_single if unit == 1 else run_steps_batch
     out = run_steps(args.warmup) if args.warmup > 0 else None
     if dist is not None and out is not None:
         # untimed: the first collective of each kind sets up its RCCL channels
@@ -500,17 +511,20 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     lib.mvf_profile_enable(0)
     stages = {k: v / n_prof for k, v in stages.items()}          # ms per sample
     M = plan.last_counts["pixels"] if splat else plan.last_counts["mappings"]
+    if batched:
+        M //= n_samples                 # the byte model below is per sample
     # depth-map visibility: one depth gather per in-view (point, view) pair; the
     # pairs that pass the test are a lower bound of those that reach it
     B = algorithmic_bytes(N, V, W, H, M, plan.F, C_feat, depth=depth, m_fov=M,
-                          Vw=plan.last_counts["mappings"])
+                          Vw=plan.last_counts["mappings"] // (n_samples if batched else 1))
     if depth:
         charged = {"point_mask": B["projection"] + B["zbuffer"], "csr_fill": B["emit"] + B["csr"],
                    "pools": B["atomic_pool"] + B["view_pool"]}
     else:
         charged = {"bin_count": B["projection"], "tile_zbuffer": B["zbuffer"],
                    "csr_fill": B["emit"] + B["csr"], "pools": B["atomic_pool"] + B["view_pool"]}
-    charged = {k: v for k, v in charged.items() if k in stages}
+    # a batched pass launches every kernel once for all samples
+    charged = {k: v * (n_samples if batched else 1) for k, v in charged.items() if k in stages}
     dom = max(charged, key=lambda k: stages.get(k, 0.0))
     ach = charged[dom] / (stages[dom] * 1e-3)
     traffic = pmc_traffic(cfg, dom)
@@ -529,7 +543,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             measured_frac=None if step_traffic is None
             else step_traffic * n_samples / (ms_step * 1e-3) / HBM_PEAK),
         stage_ms={k: round(v, 4) for k, v in stages.items()})
-    if not depth:
+    if not depth and not batched:
         # The z-buffer lives in LDS: the byte model above charges bytes that never
         # reach HBM.  What bounds the kernel is the issue rate of LDS atomics.
         plan.run()
@@ -559,7 +573,8 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
                    + f" + max atomic pool + max/mean view pools (C={C_feat}, pools fused in one pass)",
                    "name": cfg, "points_per_gpu": N_all, "views": V, "image": [W, H],
                    "samples_per_step": n_samples,
-                   "mappings_per_sample": plan.last_counts["mappings"],
+                   "batched_pass": batched,
+                   "mappings_per_sample": plan.last_counts["mappings"] // (n_samples if batched else 1),
                    "pixels_per_sample": plan.last_counts["pixels"] if splat else plan.last_counts["mappings"],
                    "splat_tile_pairs": plan.last_counts["pairs"],
                    "streams_per_gpu": n_lanes,
@@ -628,6 +643,8 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="views of the c5 scene held by this rank")
     ap.add_argument("--exact", type=int, default=1,
                     help="0: plain splat visibility (every pixel a point wins is a mapping) for c1 / c2 / c4")
+    ap.add_argument("--batched", type=int, default=1,
+                    help="c4: 1 maps the samples of a batch in one launch set, 0 one by one + torch collation")
     ap.add_argument("--lanes", type=int, default=3,
                     help="streams that consecutive samples alternate between (1 = no overlap)")
     args = ap.parse_args()

@@ -226,6 +226,39 @@ int mvf_map_images_exact(
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- *
+ * mvf_map_images_exact for a batch of samples in one launch set: MapImages
+ * applied to every sample (core/data_transform/multimodal/image.py:162-428)
+ * followed by the collation of the per-sample mappings into one
+ * ImageMappingBatch (CSRBatch.from_csr_list, core/multimodal/csr.py:347-416;
+ * SameSettingImageBatch.from_data_list, core/multimodal/image.py:1329-1405).
+ * The clouds of the samples are concatenated (xyz [n][3], every sample in its
+ * own local order), and so are their views (views [V]); all samples share the
+ * visibility parameters, image size and crop.  view_window [n][2] int32 =
+ * {first view, number of views} of the sample of point position i;
+ * view_first [V] = first view of the sample of view v; views_per_point = the
+ * largest number of views of a sample.  inv_ids [num_points]: position of
+ * every output point id (ids of sample s follow those of sample s - 1).
+ * Outputs as mvf_map_images_exact over the concatenated ids: `images` holds
+ * the rank of the view among the seen views of the whole batch, which is the
+ * image index of the collated batch once every sample has dropped its unseen
+ * views.  V <= 480, V * W * H < 2^32 - 1.
+ * ---------------------------------------------------------------------- */
+size_t mvf_map_images_batch_workspace_bytes(
+    int64_t n, int32_t V, int32_t views_per_point, int32_t W, int32_t H,
+    int64_t num_points, int64_t pair_capacity, int64_t centre_slots);
+int mvf_map_images_exact_batch(
+    const float *xyz, const int64_t *inv_ids, const int32_t *view_window,
+    int64_t n, int64_t num_points, const mvf_view *views,
+    const int32_t *view_first, int32_t V, int32_t views_per_point,
+    const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, int64_t centre_slots,
+    int64_t pair_capacity, int64_t *pointers, int64_t *images, int16_t *pixels,
+    float *features, int64_t out_capacity, int32_t *view_seen,
+    int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------- *
  * MapImages._process with SplattingVisibility(exact=False), all V views of one
  * sample in one launch set (core/data_transform/multimodal/image.py:192-428;
  * visibility_from_splatting_cpu without the exact step,

@@ -50,6 +50,7 @@ struct ArraySrc {                      // visibility_from_splatting(x_proj, y_pr
     const double *x, *y; const float *dist; const float *xyz; mvf_view view; i64 m;
     static constexpr bool ANY = true;
     __device__ i64 count() const { return m; }
+    __device__ int2 views_of(i64, int) const { return make_int2(0, 1); }
     __device__ bool get(i64 i, int, const mvf_vis_params &P, double &ox, double &oy, float &od,
                         double &sx, double &sy) const {
         ox = x[i]; oy = y[i]; od = dist[i];
@@ -62,8 +63,13 @@ struct ArraySrc {                      // visibility_from_splatting(x_proj, y_pr
 
 struct CloudSrc {                      // fused MapImages: project xyz[i] into view v
     const float *xyz; const mvf_view *views; const uint8_t *mask; i64 n; int cylinder;
+    // Batch of samples in one call: window[i] = {first view, number of views} of
+    // point position i (the views of its own sample); null = every point meets
+    // all V views.  Kernels walk a point's views by their index inside the window.
+    const int2 *window;
     static constexpr bool ANY = false;     // pinhole cameras only
     __device__ i64 count() const { return n; }
+    __device__ int2 views_of(i64 i, int V) const { return window ? window[i] : make_int2(0, V); }
     __device__ bool get(i64 i, int v, const mvf_vis_params &P, double &ox, double &oy, float &od,
                         double &sx, double &sy) const {
         const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
@@ -163,25 +169,39 @@ __device__ __forceinline__ int size_class(const BBox &b, int tx, int ty)
 // there is none), with a single barrier.  The points of a block are neighbours
 // in space, so the range is a small part of the view's tiles and the LDS
 // histogram only needs clearing and flushing there.
-struct BlockBins { unsigned rank, total; int lo, hi; };
+// `view` / `one_view`: the view of the flagged threads when they all agree (a
+// block of a batched call may hold points of two samples, whose views differ).
+struct BlockBins { unsigned rank, total; int lo, hi, view; bool one_view; };
 
-__device__ __forceinline__ BlockBins block_bins(bool have, int t_first, int t_last)
+// VIEWS = false: every thread of the block is on view v (no reduction over it).
+template <bool VIEWS>
+__device__ __forceinline__ BlockBins block_bins(bool have, int t_first, int t_last, int v)
 {
-    __shared__ int s_cnt[4], s_mn[4], s_mx[4];
+    __shared__ int s_cnt[4], s_mn[4], s_mx[4], s_vmn[4], s_vmx[4];
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 m = __ballot(have);
     int mn = have ? t_first : 0x7fffffff, mx = have ? t_last : -1;
+    int vmn = have ? v : 0x7fffffff, vmx = have ? v : -1;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const int omn = __shfl_xor(mn, d, 64), omx = __shfl_xor(mx, d, 64);
         mn = omn < mn ? omn : mn;
         mx = omx > mx ? omx : mx;
+        if (VIEWS) {
+            const int ovmn = __shfl_xor(vmn, d, 64), ovmx = __shfl_xor(vmx, d, 64);
+            vmn = ovmn < vmn ? ovmn : vmn;
+            vmx = ovmx > vmx ? ovmx : vmx;
+        }
     }
-    if (lane == 0) { s_cnt[wave] = __popcll(m); s_mn[wave] = mn; s_mx[wave] = mx; }
+    if (lane == 0) {
+        s_cnt[wave] = __popcll(m); s_mn[wave] = mn; s_mx[wave] = mx;
+        if (VIEWS) { s_vmn[wave] = vmn; s_vmx[wave] = vmx; }
+    }
     __syncthreads();
     BlockBins r;
     r.rank = __popcll(m & ((1ull << lane) - 1ull));
     r.total = 0; r.lo = 0x7fffffff; r.hi = -1;
+    int vlo = 0x7fffffff, vhi = -1;
 #pragma unroll
     for (unsigned w = 0; w < 4; ++w) {
         const int c = s_cnt[w];
@@ -189,12 +209,20 @@ __device__ __forceinline__ BlockBins block_bins(bool have, int t_first, int t_la
         r.total += c;
         r.lo = s_mn[w] < r.lo ? s_mn[w] : r.lo;
         r.hi = s_mx[w] > r.hi ? s_mx[w] : r.hi;
+        if (VIEWS) {
+            vlo = s_vmn[w] < vlo ? s_vmn[w] : vlo;
+            vhi = s_vmx[w] > vhi ? s_vmx[w] : vhi;
+        }
     }
     r.hi += 1;
+    r.view = VIEWS ? vlo : v;
+    r.one_view = VIEWS ? vlo == vhi : true;
     return r;
 }
 
-template <class Src, bool ZERO_SEEN, int NH>
+// WIN: the call is a batch of samples (src.window set): a thread's view is the
+// blockIdx.y-th of its point's window, and a block may meet two views.
+template <class Src, bool ZERO_SEEN, int NH, bool WIN = false>
 __global__ __launch_bounds__(256) void bin_count_kernel(
     Src src, mvf_vis_params P, int tiles_y, int tiles_per_view,
     unsigned *__restrict__ tile_count, uint8_t *__restrict__ seen, i64 seen_stride,
@@ -204,30 +232,33 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     __shared__ unsigned hist[NH];
     const int tid = threadIdx.x;
     const i64 i = (i64)blockIdx.x * 256 + tid;
-    const int v = blockIdx.y;
+    const int lv = blockIdx.y;             // index of the view among the views of the thread's point
     // the first block also clears the caller's small output arrays
-    if (blockIdx.x == 0 && v == 0) {
+    if (blockIdx.x == 0 && lv == 0) {
         if (zero_counters && tid < 8) zero_counters[tid] = 0;
         if (zero_view_seen) for (int k = tid; k < V; k += 256) zero_view_seen[k] = 0;
     }
     const bool live = i < src.count();
-    if (ZERO_SEEN && live && v == 0) {
+    const int2 win = WIN && live ? src.views_of(i, V) : make_int2(0, WIN ? 0 : 0x7fffffff);
+    const int v = win.x + lv;
+    if (ZERO_SEEN && live && lv == 0) {
         // flags of a point over all views: seen_stride bytes, a multiple of 16
         uint4 *row = (uint4 *)(seen + (size_t)i * seen_stride);
         for (int k = 0; k < (int)(seen_stride >> 4); ++k) row[k] = make_uint4(0u, 0u, 0u, 0u);
     }
     double x, y, sx, sy; float d = 0.f;
-    const bool have = live && src.get(i, v, P, x, y, d, sx, sy);
+    const bool have = live && lv < win.y && src.get(i, v, P, x, y, d, sx, sy);
     BBox b{0, 0, 0, 0};
     if (have) b = splat_bbox<Src::ANY>(x, y, d, sx, sy, P);
     const int tx0 = b.xa >> TILE_X_LOG, tx1 = (b.xb - 1) >> TILE_X_LOG;
     const int ty0 = b.ya >> TILE_Y_LOG, ty1 = (b.yb - 1) >> TILE_Y_LOG;
     const int ncnt = tiles_per_view * NCLS;
-    unsigned *tc = tile_count + (size_t)v * ncnt;
-    const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
+    const BlockBins bb = block_bins<WIN>(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, v);
+    // the LDS histogram holds the tiles of one view
+    unsigned *tc = tile_count + (size_t)(bb.one_view ? bb.view : v) * ncnt;
     {
         // the boxes are kept for the fill pass, packed per block
-        const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
+        const size_t blk = (size_t)lv * gridDim.x + blockIdx.x;
         if (tid == 0) staged_count[blk] = bb.total;
         if (have) {
             TileEntry e;
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     }
     if (bb.total == 0) return;
     const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
-    if (hi - lo <= NH) {
+    if (bb.one_view && hi - lo <= NH) {
         for (int t = tid; t < hi - lo; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
@@ -257,31 +288,34 @@ __global__ __launch_bounds__(256) void bin_count_kernel(
     }
 }
 
-template <int NH>
+template <int NH, bool WIN = false>
 __global__ __launch_bounds__(256) void bin_fill_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
     int tiles_y, int tiles_per_view,
     const unsigned *__restrict__ tile_off, unsigned *__restrict__ tile_cur,
-    TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow)
+    TileEntry *__restrict__ entries, i64 pair_capacity, i64 *__restrict__ overflow,
+    const int2 *__restrict__ window)
 {
     __shared__ unsigned hist[NH];        // per (tile, class): count, then absolute write cursor
     const int tid = threadIdx.x;
-    const int v = blockIdx.y;
-    const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
+    const int lv = blockIdx.y;
+    const size_t blk = (size_t)lv * gridDim.x + blockIdx.x;
     const unsigned n = staged_count[blk];
     if (n == 0) return;
     const bool have = (unsigned)tid < n;
     TileEntry e;
     e.key = 0; e.xa = e.xb = e.ya = e.yb = 0;
     if (have) e = staged[blk * 256 + tid];
+    // the view of the entry: the lv-th of its point's views
+    const int v = (WIN && have ? window[(unsigned)e.key].x : 0) + lv;
     const BBox b{(int)e.xa, (int)e.xb, (int)e.ya, (int)e.yb};
     const int tx0 = b.xa >> TILE_X_LOG, tx1 = (b.xb - 1) >> TILE_X_LOG;
     const int ty0 = b.ya >> TILE_Y_LOG, ty1 = (b.yb - 1) >> TILE_Y_LOG;
     const int ncnt = tiles_per_view * NCLS;
-    const size_t cbase = (size_t)v * ncnt;
-    const BlockBins bb = block_bins(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1);
+    const BlockBins bb = block_bins<WIN>(have, tx0 * tiles_y + ty0, tx1 * tiles_y + ty1, v);
+    const size_t cbase = (size_t)(bb.one_view ? bb.view : v) * ncnt;
     const int lo = bb.lo * NCLS, hi = bb.hi * NCLS;
-    if (hi - lo <= NH) {
+    if (bb.one_view && hi - lo <= NH) {
         for (int t = tid; t < hi - lo; t += 256) hist[t] = 0;
         __syncthreads();
         if (have)
@@ -557,7 +591,7 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
     const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
     const unsigned *__restrict__ n_desc, unsigned *__restrict__ queue, i64 pair_capacity,
     int tiles_y, int tiles_per_view, int W, int Hc, uint8_t *__restrict__ seen, i64 seen_stride,
-    unsigned *__restrict__ idmap)
+    unsigned *__restrict__ idmap, const int *__restrict__ view_first)
 {
     __shared__ __align__(16) u64 zb[ZB_KEYS];
     __shared__ unsigned s_next;
@@ -616,6 +650,8 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
         uint4 raw_n = make_uint4(0u, 0u, 0u, 0u);
 
         const int v = d.view;
+        // seen flags are indexed by the view's place among the views of its sample
+        const int lv = view_first ? v - view_first[v] : v;
         const int x0 = d.origin & 0xffffu, y0 = d.origin >> 16;
 
         i64 base = begin;
@@ -696,7 +732,7 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
                 // A winner is marked where neither the pixel above (inside the
                 // piece) nor the pixel to the left (the first lane of a row goes
                 // without) shows it: its top-left visible pixel always qualifies.
-                uint8_t *sv = seen + v;
+                uint8_t *sv = seen + lv;
                 unsigned prev = 0xffffffffu;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -1011,10 +1047,11 @@ __global__ __launch_bounds__(256) void mi_centre_kernel(
     src = views_to_lds(src, V, (mvf_view *)dyn_lds);
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= src.n) return;
-    for (int chunk = 0; chunk * 16 < V; ++chunk) {
+    const int2 win = src.views_of(i, V);
+    for (int chunk = 0; chunk * 16 < win.y; ++chunk) {
         unsigned m = seen_chunk(seen, seen_stride, i, chunk);
         while (m) {
-            const int v = 16 * chunk + __ffs(m) - 1;
+            const int v = win.x + 16 * chunk + __ffs(m) - 1;
             m &= m - 1;
             double x, y, fx, fy; float d;
             if (!src.get(i, v, P, x, y, d, fx, fy)) continue;
@@ -1100,7 +1137,7 @@ __device__ __forceinline__ void mi_pixel(
 // the kept-view bit masks masks[word][q] and the block's mapping count.
 template <class Keep>
 __global__ __launch_bounds__(256) void mi_point_mask_kernel(
-    CloudSrc src, mvf_vis_params P, Keep keep, PixelXform X, int V,
+    CloudSrc src, mvf_vis_params P, Keep keep, PixelXform X, int V, int Vw,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
@@ -1108,15 +1145,16 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
     src = views_to_lds(src, V, (mvf_view *)dyn_lds);
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 i = q < num_points ? inv_ids[q] : -1;
+    const int2 win = i >= 0 ? src.views_of(i, V) : make_int2(0, 0);
     unsigned c = 0;
-    const int words = (V + 31) >> 5;
+    const int words = (Vw + 31) >> 5;            // mask bits: a view's index inside the point's window
     for (int wd = 0; wd < words; ++wd) {
-        unsigned sm = i >= 0 ? keep.candidates(i, wd, V) : 0u;
+        unsigned sm = i >= 0 ? keep.candidates(i, wd, Vw) : 0u;
         unsigned kept = 0;
         while (sm) {
             const int bit = __ffs(sm) - 1;
             sm &= sm - 1;
-            const int v = (wd << 5) + bit;
+            const int v = win.x + (wd << 5) + bit;
             int px, py; float d; double yp;
             const int s = mi_survives(src, P, keep, X, i, v, px, py, d, yp);
             if (s) view_seen[v] = 1;
@@ -1135,7 +1173,7 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
 // front of it itself, and ranks the seen views among the seen views (lexunique
 // + bucketize, image.py:392-394) in LDS; the last block also stores the totals.
 __global__ __launch_bounds__(256) void mi_fill_kernel(
-    CloudSrc src, mvf_vis_params P, PixelXform X, int V, const i64 *__restrict__ inv_ids,
+    CloudSrc src, mvf_vis_params P, PixelXform X, int V, int Vw, const i64 *__restrict__ inv_ids,
     i64 num_points, const unsigned *__restrict__ masks, const unsigned *__restrict__ block_sums,
     const int *__restrict__ view_seen, FeatArgs A, i64 out_capacity,
     i64 *__restrict__ pointers, i64 *__restrict__ images, int16_t *__restrict__ pixels,
@@ -1155,7 +1193,7 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
     block_exclusive_scan<i64>(front, front_total);       // also orders view_rank for the block
 
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
-    const int words = (V + 31) >> 5;
+    const int words = (Vw + 31) >> 5;
     unsigned c = 0;
     if (q < num_points)
         for (int wd = 0; wd < words; ++wd) c += __popc(masks[(size_t)wd * num_points + q]);
@@ -1170,11 +1208,12 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
     pointers[q] = k;
     if (c == 0) return;
     const i64 i = inv_ids[q];
+    const int first_view = src.views_of(i, V).x;
     const float px3 = src.xyz[3 * i], py3 = src.xyz[3 * i + 1], pz3 = src.xyz[3 * i + 2];
     for (int wd = 0; wd < words; ++wd) {
         unsigned m = masks[(size_t)wd * num_points + q];
         while (m) {
-            const int v = (wd << 5) + __ffs(m) - 1;
+            const int v = first_view + (wd << 5) + __ffs(m) - 1;
             m &= m - 1;
             if (k < out_capacity) {
                 int px, py; float d; double yp;
@@ -1586,17 +1625,18 @@ static int splat_visibility_impl(
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, (int)tiles);
     hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS_WIDE>), grid_m, block, 0, st, staged, staged_count, tiles_y,
-                       (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
+                       (int)tiles, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2,
+                       (const int2 *)nullptr);
     if (P.exact) {
         hipLaunchKernelGGL((tile_zbuffer_kernel<0>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
-                           seen, (i64)1, (unsigned *)nullptr);
+                           seen, (i64)1, (unsigned *)nullptr, (const int *)nullptr);
         hipLaunchKernelGGL(centre_stamp_kernel, grid_m, block, 0, st, x_proj, y_proj, (i64)m, seen,
                            P.crop_top, Hc, idmap);
     } else {
         hipLaunchKernelGGL((tile_zbuffer_kernel<1>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                            descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, (int)tiles, P.W, Hc,
-                           (uint8_t *)nullptr, (i64)0, idmap);
+                           (uint8_t *)nullptr, (i64)0, idmap, (const int *)nullptr);
     }
     IdmapPred pred{idmap};
     IdmapEmit emit{idmap, Hc, P.crop_top, (i64 *)out_idx, (i64 *)out_x, (i64 *)out_y};
@@ -1701,13 +1741,15 @@ struct MapWorkspace {
     // and first-pixel offsets of the (point, view) pairs [n][V], pixels per block
     unsigned *idmap, *cnt;
     i64 *poff, *block_pix;
+    // Vw: views a point can meet (V, or the largest sample of a batched call)
     bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
-               i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0)
+               i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0, int Vw = 0)
     {
+        if (Vw <= 0) Vw = V;
         const i64 slots = centre_table_slots(centre_slots);
         int slots_log = 0;
         while ((1ll << slots_log) < slots) ++slots_log;
-        const int words = (V + 31) / 32;
+        const int words = (Vw + 31) / 32;
         Arena ar(workspace, workspace_bytes);
         // counters are [tile][class]; behind them: number of non-empty tiles, z-buffer tickets
         ncnt = tiles * NCLS;
@@ -1719,9 +1761,9 @@ struct MapWorkspace {
         tile_off = ar.take<unsigned>(ncnt + BIN_TAIL);
         descs = ar.take<TileDesc>(tiles + 1);
         entries = ar.take<TileEntry>(pair_capacity);
-        staged = ar.take<TileEntry>((size_t)V * cdiv(n, 256) * 256);
-        staged_count = ar.take<unsigned>((size_t)V * cdiv(n, 256));
-        seen_stride = seen_row_bytes(V);
+        staged = ar.take<TileEntry>((size_t)Vw * cdiv(n, 256) * 256);
+        staged_count = ar.take<unsigned>((size_t)Vw * cdiv(n, 256));
+        seen_stride = seen_row_bytes(Vw);
         seen = ar.take<uint8_t>((size_t)seen_stride * n);
         masks = ar.take<unsigned>((size_t)words * num_points);
         block_sums = ar.take<unsigned>(cdiv(num_points, 256));
@@ -1779,17 +1821,20 @@ extern "C" int mvf_profile_zbuffer_ops(
     return MVF_OK;
 }
 
-extern "C" int mvf_map_images_exact(
-    const float *xyz, const int64_t *point_ids, const int64_t *inv_ids, int64_t n,
+// The fused exact pass.  window / view_first / Vw describe a batch of samples
+// (null, null, V: one sample whose points meet all V views).
+static int map_images_exact_impl(
+    const float *xyz, const int64_t *inv_ids, int64_t n,
     int64_t num_points, const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
     int32_t cylinder, const uint8_t *mask, const float *linearity, const float *planarity,
     const float *scattering, const float *normals, int32_t proj_upscale, int32_t downscale,
     int32_t crop_w, int32_t crop_h, int64_t centre_slots, int64_t pair_capacity,
     int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
-    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream,
+    const int2 *window, const int *view_first, int32_t Vw)
 {
-    (void)point_ids;
     if (int rc = check_params(h_params, "map_images_exact")) return rc;
+    MVF_REQUIRE(Vw >= 1 && Vw <= V, "map_images_exact: bad views per point %d (V = %d)", Vw, V);
     MVF_REQUIRE(n >= 1 && n < (1ll << 32) - 1 && num_points >= 1 && V >= 1 && V <= MI_MAX_VIEWS,
                 "map_images_exact: bad sizes n=%lld V=%d (at most %d views per call)", (long long)n, V, MI_MAX_VIEWS);
     MVF_REQUIRE(xyz && inv_ids && views && pointers && images && pixels && features &&
@@ -1810,7 +1855,7 @@ extern "C" int mvf_map_images_exact(
     const i64 tiles = (i64)tiles_per_view * V;
     const i64 nb = cdiv(num_points, 256);
     MapWorkspace ws;
-    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, centre_slots)) {
+    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, centre_slots, 0, Vw)) {
         set_error("map_images_exact: workspace too small (%zu < %zu)", workspace_bytes, ws.used);
         return MVF_E_WORKSPACE;
     }
@@ -1827,21 +1872,30 @@ extern "C" int mvf_map_images_exact(
     MVF_HIP(hipMemsetAsync(tile_count, 0, clear_bytes, st));
     prof_mark("memset", st);
 
-    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
-    dim3 grid_nv(cdiv(n, 256), V), block(256);
-    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
-                       tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
-                       staged_count);
+    CloudSrc src{xyz, views, mask, (i64)n, cylinder, window};
+    dim3 grid_nv(cdiv(n, 256), Vw), block(256);
+    if (window)
+        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS, true>), grid_nv, block, 0, st, src, P, tiles_y,
+                           tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
+                           staged_count);
+    else
+        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
+                           tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
+                           staged_count);
     prof_mark("bin_count", st);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(cdiv(tiles, 1024)), dim3(1024), 0, st, tile_count, tiles, tile_off, tile_cur,
                        descs, tile_count + ncnt, (i64 *)counters + 1, tiles_y, tiles_per_view);
     prof_mark("tile_scan", st);
-    hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, staged, staged_count, tiles_y,
-                       tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2);
+    if (window)
+        hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS, true>), grid_nv, block, 0, st, staged, staged_count, tiles_y,
+                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2, window);
+    else
+        hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, staged, staged_count, tiles_y,
+                           tiles_per_view, tile_off, tile_cur, entries, (i64)pair_capacity, (i64 *)counters + 2, window);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<0>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, entries,
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
-                       seen, seen_stride, (unsigned *)nullptr);
+                       seen, seen_stride, (unsigned *)nullptr, view_first);
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, V, Hc,
                        table, (i64 *)counters + 2);
@@ -1850,10 +1904,10 @@ extern "C" int mvf_map_images_exact(
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
     hipLaunchKernelGGL((mi_point_mask_kernel<SplatKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
-                       SplatKeep{seen, seen_stride, table, Hc}, X, V, (const i64 *)inv_ids, (i64)num_points,
+                       SplatKeep{seen, seen_stride, table, Hc}, X, V, Vw, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, Vw,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
@@ -1861,6 +1915,54 @@ extern "C" int mvf_map_images_exact(
     prof_mark("csr_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_map_images_exact(
+    const float *xyz, const int64_t *point_ids, const int64_t *inv_ids, int64_t n,
+    int64_t num_points, const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
+    int32_t cylinder, const uint8_t *mask, const float *linearity, const float *planarity,
+    const float *scattering, const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, int64_t centre_slots, int64_t pair_capacity,
+    int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    (void)point_ids;
+    return map_images_exact_impl(
+        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
+        normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
+        pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
+        (const int2 *)nullptr, (const int *)nullptr, V);
+}
+
+// A batch of samples in one launch set: the clouds concatenated, the views
+// concatenated, every point facing the views of its own sample only.
+extern "C" size_t mvf_map_images_batch_workspace_bytes(
+    int64_t n, int32_t V, int32_t views_per_point, int32_t W, int32_t H, int64_t num_points,
+    int64_t pair_capacity, int64_t centre_slots)
+{
+    const i64 tiles = (i64)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
+    MapWorkspace ws;
+    ws.carve(nullptr, 0, n > 0 ? n : 1, V, tiles, num_points > 0 ? num_points : 1,
+             pair_capacity > 0 ? pair_capacity : 1, centre_slots, 0, views_per_point);
+    return ws.used;
+}
+
+extern "C" int mvf_map_images_exact_batch(
+    const float *xyz, const int64_t *inv_ids, const int32_t *view_window, int64_t n,
+    int64_t num_points, const mvf_view *views, const int32_t *view_first, int32_t V,
+    int32_t views_per_point, const mvf_vis_params *h_params,
+    int32_t cylinder, const uint8_t *mask, const float *linearity, const float *planarity,
+    const float *scattering, const float *normals, int32_t proj_upscale, int32_t downscale,
+    int32_t crop_w, int32_t crop_h, int64_t centre_slots, int64_t pair_capacity,
+    int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MVF_REQUIRE(view_window && view_first, "map_images_exact_batch: null view window");
+    return map_images_exact_impl(
+        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
+        normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
+        pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
+        (const int2 *)view_window, (const int *)view_first, views_per_point);
 }
 
 // MapImages with DepthBasedVisibility, all views in one launch set: no z-buffer
@@ -1908,10 +2010,10 @@ extern "C" int mvf_map_images_depth(
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb), block(256);
     hipLaunchKernelGGL((mi_point_mask_kernel<DepthKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
-                       DepthKeep{depth_maps}, X, V, (const i64 *)inv_ids, (i64)num_points, masks, block_sums,
+                       DepthKeep{depth_maps}, X, V, V, (const i64 *)inv_ids, (i64)num_points, masks, block_sums,
                        view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V,
+    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, V,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
@@ -1981,11 +2083,11 @@ extern "C" int mvf_map_images_splat(
     prof_mark("tile_scan", st);
     hipLaunchKernelGGL((bin_fill_kernel<BIN_LDS>), grid_nv, block, 0, st, ws.staged, ws.staged_count, tiles_y,
                        tiles_per_view, ws.tile_off, ws.tile_cur, ws.entries, (i64)pair_capacity,
-                       (i64 *)counters + 2);
+                       (i64 *)counters + 2, (const int2 *)nullptr);
     prof_mark("bin_fill", st);
     hipLaunchKernelGGL((tile_zbuffer_kernel<2>), dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, st, ws.entries,
                        ws.descs, ws.tile_count + ncnt, ws.tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity,
-                       tiles_y, tiles_per_view, P.W, Hc, ws.seen, ws.seen_stride, ws.idmap);
+                       tiles_y, tiles_per_view, P.W, Hc, ws.seen, ws.seen_stride, ws.idmap, (const int *)nullptr);
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL((ne_scan_kernel<false>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
                        ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,

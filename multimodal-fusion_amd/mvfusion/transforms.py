@@ -141,8 +141,14 @@ class FusedMapPlan:
 
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
-                 lane=0, centre_slots=None, depth_maps=None, pix_cap=None):
+                 lane=0, centre_slots=None, depth_maps=None, pix_cap=None, window=None,
+                 view_first=None, views_per_point=None):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
+        # a batch of samples in one pass (mvf_map_images_exact_batch): window
+        # [N, 2] int32 = (first view, number of views) of every point position,
+        # view_first [V] int32 = first view of the sample of every view
+        self.window, self.view_first = window, view_first
+        self.views_per_point = views_per_point or V
         # [V, W, H] float32 depth maps: the pass then runs DepthBasedVisibility
         # (mvf_map_images_depth) instead of the exact splat visibility
         self.depth_maps = depth_maps
@@ -151,11 +157,12 @@ class FusedMapPlan:
             cylinder, upscale, downscale, crop_size
         self.N, self.V, self.num_points, self.device = pos.shape[0], V, num_points, device
         self.F = 2 + sum(a is not None for a in attrs)
-        self.pair_cap = pair_cap or (self.N * V // 4 + 4096)
-        self.out_cap = out_cap or (self.N * V // 4 + 4096)
+        pairs = self.N * self.views_per_point            # (point, view) pairs of the pass
+        self.pair_cap = pair_cap or (pairs // 4 + 4096)
+        self.out_cap = out_cap or (pairs // 4 + 4096)
         # slots of the table that resolves shared centre pixels (the library
         # rounds up to a power of two); fitted to the mappings after a run
-        self.centre_slots = centre_slots or max(self.N * V // 8, 65536)
+        self.centre_slots = centre_slots or max(pairs // 8, 65536)
         # plain splat visibility (params.exact == 0): every pixel a point wins is
         # a mapping; room for that many pixels (at most one per image pixel)
         self.splat = depth_maps is None and not params.exact
@@ -166,6 +173,43 @@ class FusedMapPlan:
         self.last_counts = None
         self.lane = lane
 
+    @staticmethod
+    def batched(plans):
+        """One plan over the samples of ``plans`` (exact splat visibility, same
+        image settings): clouds and views concatenated, every point facing the
+        views of its own sample (``mvf_map_images_exact_batch``).  The outputs are
+        the CSR of the collated batch.  None when the samples cannot share a
+        pass."""
+        first = plans[0]
+        key = lambda p: (bytes(p.params), p.cylinder, p.upscale, p.downscale, tuple(p.crop_size),
+                         [a is not None for a in p.attrs], p.device)
+        def same_mask(p):
+            if p.mask is None or first.mask is None:
+                return p.mask is first.mask
+            return p.mask is first.mask or torch.equal(p.mask, first.mask)
+        if any(p.depth_maps is not None or p.splat or p.window is not None or not same_mask(p)
+               or key(p) != key(first) for p in plans):
+            return None
+        n_views = [p.V for p in plans]
+        V = sum(n_views)
+        if V > 480 or V * first.params.W * first.params.H >= 2 ** 32 - 1:
+            return None
+        dev = first.device
+        n_pos = [p.N for p in plans]
+        pos0 = np.concatenate(([0], np.cumsum(n_pos)))
+        view0 = np.concatenate(([0], np.cumsum(n_views)))
+        inv = torch.cat([torch.where(p.inv >= 0, p.inv + int(o), p.inv) for p, o in zip(plans, pos0)])
+        attrs = [torch.cat([p.attrs[k] for p in plans]) if first.attrs[k] is not None else None
+                 for k in range(len(first.attrs))]
+        window = torch.from_numpy(np.repeat(
+            np.stack([view0[:-1], n_views], axis=1).astype(np.int32), n_pos, axis=0)).to(dev)
+        view_first = torch.from_numpy(np.repeat(view0[:-1].astype(np.int32), n_views)).to(dev)
+        return FusedMapPlan(
+            torch.cat([p.pos for p in plans]), None, inv.contiguous(), attrs,
+            torch.cat([p.views for p in plans]), first.mask, first.params, first.cylinder,
+            first.upscale, first.downscale, first.crop_size, V, sum(p.num_points for p in plans), dev,
+            window=window, view_first=view_first, views_per_point=max(n_views))
+
     def twin(self, lane):
         """A second plan over the same staged sample with its own outputs,
         and workspace, to be driven on another stream."""
@@ -173,7 +217,8 @@ class FusedMapPlan:
             self.pos, self.ids, self.inv, self.attrs, self.views, self.mask, self.params,
             self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
             self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane,
-            centre_slots=self.centre_slots, depth_maps=self.depth_maps, pix_cap=self.pix_cap)
+            centre_slots=self.centre_slots, depth_maps=self.depth_maps, pix_cap=self.pix_cap,
+            window=self.window, view_first=self.view_first, views_per_point=self.views_per_point)
 
     def _slot(self, k):
         """Output buffers of slot k: (capacities, counters, host counters, event,
@@ -206,6 +251,10 @@ class FusedMapPlan:
             elif self.splat:
                 ws_bytes = lib.mvf_map_images_splat_workspace_bytes(
                     self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
+            elif self.window is not None:
+                ws_bytes = lib.mvf_map_images_batch_workspace_bytes(
+                    self.N, self.V, self.views_per_point, self.params.W, self.params.H,
+                    self.num_points, self.pair_cap, self.centre_slots)
             else:
                 ws_bytes = lib.mvf_map_images_workspace_bytes(
                     self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
@@ -242,6 +291,18 @@ class FusedMapPlan:
                     L.ptr(pointers), L.ptr(img_ids), L.ptr(pixels), L.ptr(feats), self.out_cap,
                     L.ptr(view_seen), L.ptr(counters), L.ptr(ws), ws.numel(),
                     L.stream_ptr(self.device)))
+            return sl
+        if self.window is not None:
+            with torch.cuda.device(self.device):
+                L.check(lib.mvf_map_images_exact_batch(
+                    L.ptr(self.pos), L.ptr(self.inv), L.ptr(self.window), self.N, self.num_points,
+                    L.ptr(self.views), L.ptr(self.view_first), self.V, self.views_per_point,
+                    C.byref(P), int(self.cylinder), L.ptr(self.mask),
+                    *[L.ptr(a) for a in self.attrs], self.upscale, self.downscale,
+                    int(self.crop_size[0]), int(self.crop_size[1]), self.centre_slots,
+                    self.pair_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(pixels),
+                    L.ptr(feats), self.out_cap, L.ptr(view_seen), L.ptr(counters),
+                    L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
             return sl
         with torch.cuda.device(self.device):
             L.check(lib.mvf_map_images_exact(
@@ -425,6 +486,82 @@ class MapImages(ImageTransform):
             if out is not None:
                 return out
         return super(MapImages, self).__call__(data, images)
+
+    # ------------------------------------------------------------------ #
+    def prepare_batch(self, data_list, images_list, device=None):
+        """Stage a list of samples for one batched pass (``mvf_map_images_exact_batch``):
+        clouds and views concatenated, every point facing the views of its own
+        sample.  Returns (plan, per-sample bookkeeping), or None when the samples
+        cannot share a pass (different image settings, a mode other than the
+        exact splat visibility, repeated mapping ids, too many views)."""
+        device = device or L.require_device(data_list[0].pos)
+        parts, models = [], []
+        for data, images in zip(data_list, images_list):
+            if isinstance(images, ImageData):
+                return None
+            visi_model = self._settle(data, images)
+            if not self._fusable(images, visi_model) or self.method != 'SplattingVisibility' \
+                    or not visi_model.exact:
+                return None
+            plan = self.prepare_fused(data, images, visi_model, device)
+            if plan is None:
+                return None
+            parts.append(plan)
+            models.append(visi_model)
+        first = images_list[0]
+        if not all(im.mask is first.mask for im in images_list):
+            return None
+        plan = FusedMapPlan.batched(parts)
+        if plan is None:
+            return None
+        n_ids, n_views = [p.num_points for p in parts], [p.V for p in parts]
+        return plan, dict(n_ids=n_ids, n_views=n_views, models=models)
+
+    def process_batch(self, data_list, images_list):
+        """MapImages on every sample of a list and the collation of the results,
+        as one pass on the device: returns ``(data_list, SameSettingImageBatch)``
+        whose ``mappings`` are the ``ImageMappingBatch`` that
+        ``SameSettingImageBatch.from_data_list`` builds from the samples mapped
+        one by one (image.py:162-428 per sample, then core/multimodal/image.py:1329-1405
+        and core/multimodal/csr.py:347-416).  Samples that cannot share a pass
+        are mapped one by one and collated."""
+        from .images import SameSettingImageBatch
+        from .csr import CSRBatch, CSRData
+        from .mapping import ImageMappingBatch
+        staged = self.prepare_batch(data_list, images_list)
+        if staged is None:
+            out = [super(MapImages, self).__call__(d, im) for d, im in zip(data_list, images_list)]
+            return [o[0] for o in out], SameSettingImageBatch.from_data_list([o[1] for o in out])
+        plan, info = staged
+        pointers, img_ids, pixels, feats, view_seen = plan.run()[:5]
+        id0 = np.concatenate(([0], np.cumsum(info['n_ids'])))
+        # rows of every sample, and which of its views were seen: one small read-back
+        bounds = pointers[torch.from_numpy(id0).to(pointers.device)].tolist()
+        rows = np.diff(bounds)
+        if (rows == 0).any():
+            raise ValueError(_NO_MAPPING_MSG)
+        seen = (view_seen > 0).cpu()
+        kept, v0 = [], 0
+        for images, visi_model, nv in zip(images_list, info['models'], info['n_views']):
+            s = torch.where(seen[v0:v0 + nv])[0]
+            v0 += nv
+            images = images[s.to(images.device)] if s.shape[0] != nv else images
+            images.mappings = None
+            images.visibility = visi_model
+            kept.append(images)
+        batch = SameSettingImageBatch.from_data_list(kept)
+        nested = CSRBatch(torch.arange(img_ids.shape[0] + 1, dtype=torch.int64, device=pointers.device),
+                          pixels, dense=False)
+        nested.__sizes__ = torch.from_numpy(rows.astype(np.int64))
+        nested.__csr_type__ = CSRData
+        mappings = ImageMappingBatch(pointers, img_ids, nested, feats, dense=False,
+                                     is_index_value=[True, False, False])
+        mappings.__sizes__ = torch.tensor(info['n_ids'], dtype=torch.int64)
+        mappings.__csr_type__ = ImageMappingBatch.__csr_type__
+        batch.mappings = mappings.to(
+            kept[0].device if self.output_device is None else torch.device(self.output_device))
+        batch.visibility = info['models'][0]
+        return list(data_list), batch
 
     def _process_list_fused(self, data_list, images_list):
         """A list of independent samples on the fused path: the passes are

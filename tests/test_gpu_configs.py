@@ -416,6 +416,65 @@ def test_map_images_list_of_samples_multi_stream():
     check_mapping(out_list[1].mappings, ref, features_atol=1e-6)
 
 
+def test_map_images_process_batch_equals_collated_samples():
+    """One batched pass over a list of cylinders (mvf_map_images_exact_batch:
+    clouds and views concatenated, every point facing the views of its own
+    sample) returns the batch that mapping the samples one by one and collating
+    them gives: samples of different sizes and view counts (more than 16, so
+    that the flags of a point span two chunks), one with a camera that sees
+    nothing (dropped from the batch) and mapping ids that leave gaps."""
+    from mvfusion.images import SameSettingImageBatch
+    from mvfusion.mapping import ImageMappingBatch
+    from mvfusion.transforms import MapImages
+    specs = [(30000, 8), (777, 3), (41000, 19), (20000, 5)]
+    scenes = [S.make_scene("c1", seed=60 + k, n_points=n, n_views=v) for k, (n, v) in enumerate(specs)]
+    # a camera far away from the second sample: one unseen view
+    scenes[1]["pos"] = scenes[1]["pos"].copy()
+    scenes[1]["pos"][1] += 500.0
+    scenes[1]["extrinsic"] = scenes[1]["extrinsic"].copy()
+    scenes[1]["extrinsic"][1, :3, 3] += 500.0
+
+    def inputs():
+        out = []
+        for k, sc in enumerate(scenes):
+            n = sc["xyz"].shape[0]
+            ids = np.arange(n) if k != 3 else np.random.default_rng(5).permutation(n + 300)[:n]
+            out.append(make_inputs(sc["xyz"], ids, sc, sc["img_size"], attrs=True))
+        return [o[0] for o in out], [o[1] for o in out]
+
+    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, lanes=1, **VIS)
+    data, images = inputs()
+    want = SameSettingImageBatch.from_data_list([t(d, im)[1] for d, im in zip(data, images)])
+    data, images = inputs()
+    _, got = t.process_batch(data, images)
+    assert t.prepare_batch(*inputs()) is not None          # the batched pass, not the fallback
+    assert isinstance(got, SameSettingImageBatch) and isinstance(got.mappings, ImageMappingBatch)
+    assert got.num_views == want.num_views == sum(v for _, v in specs) - 1
+    assert np.array_equal(got.batch_items_sizes, want.batch_items_sizes)
+    assert torch.equal(got.pos, want.pos) and torch.equal(got.extrinsic, want.extrinsic)
+    gm, wm = got.mappings, want.mappings
+    assert torch.equal(gm.pointers, wm.pointers)
+    assert torch.equal(gm.images, wm.images)
+    assert torch.equal(gm.values[1].pointers, wm.values[1].pointers)
+    assert torch.equal(gm.pixels, wm.pixels)
+    assert torch.equal(gm.features, wm.features)
+    assert torch.equal(gm.batch_items_sizes, wm.batch_items_sizes)
+    assert torch.equal(gm.values[1].batch_items_sizes, wm.values[1].batch_items_sizes)
+    # the batch splits back into the samples
+    back = got.mappings.to_csr_list()
+    data, images = inputs()
+    for k, m in enumerate(back):
+        _, one = t(data[k], images[k])
+        assert torch.equal(m.pointers, one.mappings.pointers), k
+        assert torch.equal(m.images, one.mappings.images), k
+        assert torch.equal(m.pixels, one.mappings.pixels), k
+        assert torch.equal(m.features, one.mappings.features), k
+    # samples that cannot share a pass fall back to the loop + collation
+    data, images = inputs()
+    images[2].proj_upscale = 2
+    assert t.prepare_batch(data, images) is None
+
+
 def test_neighborhood_mapping_features():
     """NeighborhoodBasedMappingFeatures on the GPU: against the reference's
     output (fixture) and, on a C1-sized cloud mapped by MapImages, against the
