@@ -1244,6 +1244,60 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
 // (one block per 256 points and view), so nothing is projected again.
 // FILL = false: cnt[i][v] <- pixels of the pair inside the crop.
 // FILL = true: pixels[poff[i][v] ...] <- those pixels.
+#ifndef MVF_NE_ITEMS
+#define MVF_NE_ITEMS 8
+#endif
+constexpr int NE_ITEMS = MVF_NE_ITEMS;     // id-map reads of a box in flight per lane
+
+// A box is walked as (column, 16-row piece) items in ascending (x, y) order.
+// The items [first, first + NE_ITEMS) of box b for one row of 16 lanes: the
+// id-map reads are independent and go out together; then, item by item, the
+// lanes' verdicts as a 16-bit mask.  Returns the pixels of the items that the
+// id map attributes to `id` (inside the crop).
+struct NeItems { unsigned m[NE_ITEMS]; int px[NE_ITEMS], py[NE_ITEMS]; };
+struct NeView { const unsigned *idmap; int v, W, Hc, crop_top, crop_w, crop_h, off_x, off_y; };
+
+__device__ __forceinline__ unsigned ne_eval(
+    const TileEntry &b, unsigned id, const NeView &S, int first, int n_items, int nch, unsigned ly,
+    unsigned sh, NeItems &I)
+{
+    int cx = first / nch, cy = first - cx * nch;          // column and piece of the next item
+    unsigned val[NE_ITEMS];
+    bool in[NE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < NE_ITEMS; ++k) {
+        const int x = (int)b.xa + cx, y = (int)b.ya + 16 * cy + (int)ly;
+        I.px[k] = x - S.off_x;
+        I.py[k] = y + S.crop_top - S.off_y;
+        in[k] = first + k < n_items && y < (int)b.yb && I.px[k] >= 0 && I.px[k] < S.crop_w &&
+                I.py[k] >= 0 && I.py[k] < S.crop_h;
+        val[k] = in[k] ? S.idmap[((size_t)S.v * S.W + x) * S.Hc + y] : 0u;
+        if (++cy == nch) { cy = 0; ++cx; }
+    }
+    unsigned count = 0;
+#pragma unroll
+    for (int k = 0; k < NE_ITEMS; ++k) {
+        const bool ok = in[k] && val[k] == id + 1u;
+        I.m[k] = (unsigned)(__ballot(ok) >> sh) & 0xffffu;      // this row of 16 lanes
+        count += __popc(I.m[k]);
+    }
+    return count;
+}
+
+// Stores the pixels of evaluated items from position `pos` on.
+__device__ __forceinline__ void ne_emit(
+    const NeItems &I, i64 pos, unsigned ly, int16_t *__restrict__ pixels, i64 pix_capacity)
+{
+#pragma unroll
+    for (int k = 0; k < NE_ITEMS; ++k) {
+        if ((I.m[k] >> ly) & 1u) {
+            const i64 at = pos + __popc(I.m[k] & ((1u << ly) - 1u));
+            if (at < pix_capacity) { pixels[2 * at] = (int16_t)I.px[k]; pixels[2 * at + 1] = (int16_t)I.py[k]; }
+        }
+        pos += __popc(I.m[k]);
+    }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void ne_scan_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
@@ -1269,26 +1323,24 @@ __global__ __launch_bounds__(256) void ne_scan_kernel(
     if (have) list[rank] = e;
     __syncthreads();
     const unsigned quarter = tid >> 4, ly = tid & 15, sh = 16u * ((tid >> 4) & 3u);
-    const int off_x = views[v].crop_off_x, off_y = views[v].crop_off_y;
+    const NeView S{idmap, v, W, Hc, crop_top, crop_w, crop_h, views[v].crop_off_x, views[v].crop_off_y};
+    auto items_of = [](const TileEntry &b, int &nch) {
+        nch = ((int)b.yb - (int)b.ya + 15) >> 4;
+        return ((int)b.xb - (int)b.xa) * nch;
+    };
+    // one box per row of 16 lanes
     for (unsigned r = quarter; r < total; r += 16u) {
         const TileEntry b = list[r];
+        int nch;
+        const int n_items = items_of(b, nch);
         const unsigned id = (unsigned)b.key;
         const i64 base = FILL ? poff[(size_t)id * V + v] : 0;
         unsigned count = 0;
-        for (int x = b.xa; x < (int)b.xb; ++x) {
-            const int px = x - off_x;
-            if (px < 0 || px >= crop_w) continue;
-            const unsigned *col = idmap + ((size_t)v * W + x) * Hc;
-            for (int y0 = b.ya; y0 < (int)b.yb; y0 += 16) {
-                const int y = y0 + (int)ly, py = y + crop_top - off_y;
-                const bool ok = y < (int)b.yb && col[y] == id + 1u && py >= 0 && py < crop_h;
-                const unsigned m = (unsigned)(__ballot(ok) >> sh) & 0xffffu;      // this row of 16 lanes
-                if (FILL && ok) {
-                    const i64 pos = base + count + __popc(m & ((1u << ly) - 1u));
-                    if (pos < pix_capacity) { pixels[2 * pos] = (int16_t)px; pixels[2 * pos + 1] = (int16_t)py; }
-                }
-                count += __popc(m);
-            }
+        for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
+            NeItems I;
+            const unsigned c = ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
+            if (FILL) ne_emit(I, base + count, ly, pixels, pix_capacity);
+            count += c;
         }
         if (!FILL && ly == 0) cnt[(size_t)id * V + v] = count;
     }
@@ -1329,6 +1381,47 @@ __global__ __launch_bounds__(256) void ne_point_kernel(
     block_exclusive_scan<unsigned>(rows, rows_total);
     block_exclusive_scan<i64>(pix, pix_total);
     if (threadIdx.x == 0) { block_rows[blockIdx.x] = rows_total; block_pix[blockIdx.x] = pix_total; }
+}
+
+// f + f + ... + f (c terms, every partial sum rounded to float32, in order): what
+// a sequential segment sum over c rows that all hold f returns.  Inside a binade
+// the rounded increment is the same at every step once the sum has taken two
+// steps there (a tie rounds to even, and from an even sum the next tie falls
+// the same way), so the walk jumps through a binade with one division and
+// takes real additions only around the binade changes: O(log c) steps.
+__device__ __forceinline__ float repeat_add(float f, unsigned c)
+{
+    float s = f;
+    unsigned left = c - 1u;
+    if (!(f > 0.f) || (__float_as_uint(f) >> 23) == 0u || (__float_as_uint(f) >> 23) == 255u) {
+        for (; left; --left) s = __fadd_rn(s, f);      // zero, negative, subnormal, not finite: plain walk
+        return s;
+    }
+    while (left) {
+        const float s1 = __fadd_rn(s, f);
+        --left;
+        s = s1;
+        if (!left) break;
+        const unsigned E = __float_as_uint(s1) >> 23;
+        if (E == 255u) continue;
+        const float s2 = __fadd_rn(s1, f);
+        --left;
+        s = s2;
+        if (!left || (__float_as_uint(s2) >> 23) != E) continue;
+        const float s3 = __fadd_rn(s2, f);
+        --left;
+        s = s3;
+        if (!left || (__float_as_uint(s3) >> 23) != E) continue;
+        const unsigned m2 = (__float_as_uint(s2) & 0x7fffffu) | 0x800000u;
+        const unsigned m3 = (__float_as_uint(s3) & 0x7fffffu) | 0x800000u;
+        const unsigned d = m3 - m2;
+        if (d == 0u) break;                            // f no longer moves the sum
+        const unsigned room = (0xffffffu - m3) / d;
+        const unsigned k = left < room ? left : room;
+        left -= k;
+        s = __uint_as_float((E << 23) | ((m3 + k * d) & 0x7fffffu));
+    }
+    return s;
 }
 
 // Pointers, images, view pointers and view features (mean over the view's
@@ -1401,11 +1494,8 @@ __global__ __launch_bounds__(256) void ne_fill_kernel(
                 src.get(i, v, P, x, y, d, fx, fy);
                 float f[8];
                 write_features(f, A, i, px3, py3, pz3, src.views[v].img_xyz, d, y);
-                for (int j = 0; j < A.F; ++j) {
-                    float sum = f[j];
-                    for (unsigned t = 1; t < c; ++t) sum = __fadd_rn(sum, f[j]);
-                    features[(size_t)k * A.F + j] = __fdiv_rn(sum, (float)c);
-                }
+                for (int j = 0; j < A.F; ++j)
+                    features[(size_t)k * A.F + j] = __fdiv_rn(repeat_add(f[j], c), (float)c);
                 images[k] = view_rank[v];
                 view_ptr[k] = p;
             }

@@ -100,6 +100,56 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
     }
 }
 
+// max / min over long segments (many rows per segment, e.g. the pixels of a
+// splat): the serial walk above keeps one thread on a segment and is bound by
+// its chain of loads.  Here a wave takes a segment: lane = (row group, channel)
+// with 64 >> cp_log row groups of 1 << cp_log >= min(C, 64) channels, four steps
+// of rows in flight, and a final combine across the row groups.  Ties (+0.0 /
+// -0.0 compare equal) go to the first row, as in the in-order fold, so the
+// result is bit-identical to segment_csr_kernel's.
+template <int MODE>
+__global__ __launch_bounds__(256) void segment_long_kernel(
+    const float *__restrict__ src, int C, int cp_log, const i64 *__restrict__ ptr, i64 nseg,
+    float *__restrict__ out)
+{
+    const i64 seg = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const int lane = threadIdx.x & 63;
+    const int cp = 1 << cp_log, rp = 64 >> cp_log;
+    const int c = lane & (cp - 1), ro = lane >> cp_log;
+    const i64 a = ptr[seg], b = ptr[seg + 1];
+    auto better = [](float x, float y) { return MODE == MVF_REDUCE_MAX ? x > y : x < y; };
+    for (int c0 = 0; c0 < C; c0 += cp) {
+        const int ch = c0 + c;
+        const bool live = ch < C;
+        float acc = 0.f;
+        unsigned at = 0xffffffffu;                    // row (relative to a) the value comes from
+        const float *q = src + (size_t)a * C + ch;
+        const unsigned n = (unsigned)(b - a);
+        for (unsigned r = (unsigned)ro; r < n && live; r += 4u * (unsigned)rp) {
+            float x[4];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ok[k] = r + (unsigned)(k * rp) < n;
+                x[k] = ok[k] ? q[(size_t)(r + (unsigned)(k * rp)) * C] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ok[k] && (at == 0xffffffffu || better(x[k], acc))) { acc = x[k]; at = r + (unsigned)(k * rp); }
+        }
+        // combine the row groups (lane bits cp_log .. 5)
+        for (int d = 32; d >= cp; d >>= 1) {
+            const float ov = __shfl_xor(acc, d, 64);
+            const unsigned oat = __shfl_xor(at, d, 64);
+            const bool take = oat != 0xffffffffu &&
+                (at == 0xffffffffu || better(ov, acc) || (!better(acc, ov) && oat < at));
+            if (take) { acc = ov; at = oat; }
+        }
+        if (ro == 0 && live) out[(size_t)seg * C + ch] = at == 0xffffffffu ? 0.f : acc;
+    }
+}
+
 // Two pooling levels in one pass:
 //   out_x = segment_csr(segment_csr(src, inner_ptr, INNER), outer_ptr, reduce_x)
 // for up to two outer reductions, without the [n_inner][C] intermediate and
@@ -491,8 +541,21 @@ extern "C" int mvf_segment_csr(
     MVF_REQUIRE(ptr && out && (src || rows == 0), "segment_csr: null pointer");
     int vec, lpr_log;
     pick_layout(src, out, C, vec, lpr_log);
-    dim3 grid(cdiv(nseg * (C / vec), 256 * SEG_ILP)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if ((reduce == MVF_REDUCE_MAX || reduce == MVF_REDUCE_MIN) && rows >= 16 * nseg) {
+        // long segments on average: a wave per segment
+        int cp_log = 0;
+        while ((1 << cp_log) < C && cp_log < 6) ++cp_log;
+        if (reduce == MVF_REDUCE_MAX)
+            hipLaunchKernelGGL((segment_long_kernel<MVF_REDUCE_MAX>), dim3(cdiv(nseg, 4)), dim3(256), 0, st, src, C,
+                               cp_log, (const i64 *)ptr, (i64)nseg, out);
+        else
+            hipLaunchKernelGGL((segment_long_kernel<MVF_REDUCE_MIN>), dim3(cdiv(nseg, 4)), dim3(256), 0, st, src, C,
+                               cp_log, (const i64 *)ptr, (i64)nseg, out);
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
+    dim3 grid(cdiv(nseg * (C / vec), 256 * SEG_ILP)), block(256);
 #define MVF_SEG(V_, M_) \
     hipLaunchKernelGGL((segment_csr_kernel<V_, M_>), grid, block, 0, st, src, C, (const i64 *)ptr, (i64)nseg, out)
 #define MVF_SEG_MODE(V_)                                        \

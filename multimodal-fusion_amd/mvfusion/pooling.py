@@ -125,6 +125,16 @@ def segment_csr_two_level(src, inner_ptr, outer_ptr, inner="max", outer=("max",)
     outs = [torch.empty((n_outer, C_), dtype=torch.float32, device=src_c.device) for _ in outer]
     if n_outer > 0 and C_ > 0:
         lib = L.load()
+        if inner in ("max", "min") and n_inner > 0 and rows >= 16 * n_inner:
+            # long inner segments (the pixels of whole splats): a thread per output
+            # value would walk them alone; the inner level goes through the
+            # wave-per-segment reduction first (same values: max / min do not round)
+            view = torch.empty((n_inner, C_), dtype=torch.float32, device=src_c.device)
+            with torch.cuda.device(src_c.device):
+                L.check(lib.mvf_segment_csr(L.ptr(src_c), rows, C_, L.ptr(iptr), n_inner,
+                                            L.REDUCE[inner], L.ptr(view), L.stream_ptr(src_c.device)))
+            src_c, rows = view, n_inner
+            iptr = torch.arange(n_inner + 1, dtype=torch.int64, device=src_c.device)
         with torch.cuda.device(src_c.device):
             L.check(lib.mvf_segment_csr_two_level(
                 L.ptr(src_c), rows, C_, L.ptr(iptr), n_inner, L.REDUCE[inner], L.ptr(optr), n_outer,

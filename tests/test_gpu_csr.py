@@ -110,6 +110,39 @@ def test_gather_atomic_pool_vs_indexing(golden, mode):
             np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_segment_csr_long_segments(mode):
+    """max / min over long segments (a wave per segment instead of a thread per
+    output value): bit-equal to the oracle's in-order fold for 1, 13, 64 and 96
+    channels, with empty and one-row segments in between, values quantised so
+    that ties are frequent, and signed zeros (a tie between +0.0 and -0.0 goes
+    to the first row); then the two-level pool over such inner segments."""
+    import mvf_oracle as orc
+    from mvfusion.pooling import segment_csr, segment_csr_two_level
+    rng = np.random.default_rng(17)
+    nseg = 3000
+    sizes = rng.integers(20, 200, nseg)
+    sizes[rng.random(nseg) < 0.05] = 0
+    sizes[rng.random(nseg) < 0.05] = 1
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    assert ptr[-1] >= 16 * nseg
+    for C_ in (1, 13, 64, 96):
+        x = np.round(rng.normal(size=(int(ptr[-1]), C_)) * 4).astype(np.float32) / 4
+        x[rng.random(x.shape) < 0.3] = 0.0
+        x[rng.random(x.shape) < 0.1] = -0.0
+        got = N(segment_csr(T(x), T(ptr), reduce=mode))
+        want = orc.segment_csr(x, ptr, mode)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), C_
+    outer_sizes = rng.integers(0, 5, 900)
+    optr = np.concatenate([[0], np.cumsum(outer_sizes)]).astype(np.int64)
+    n_inner = int(optr[-1])
+    x = rng.random((int(ptr[n_inner]), 13)).astype(np.float32) - 0.5
+    got = segment_csr_two_level(T(x), T(ptr[:n_inner + 1]), T(optr), inner=mode, outer=("max", "mean"))
+    mid = orc.segment_csr(x, ptr[:n_inner + 1], mode)
+    assert np.array_equal(N(got[0]), orc.segment_csr(mid, optr, "max"))
+    np.testing.assert_allclose(N(got[1]), orc.segment_csr(mid, optr, "mean"), rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("inner", ["max", "mean", "min", "sum"])
 def test_segment_csr_two_level_equals_two_passes(inner):
     """One-pass two-level pool == two segment_csr calls, bit for bit, and == the
