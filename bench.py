@@ -70,6 +70,9 @@ class Data:
 def host_sample(scene, seed, n_views=None):
     """Synthetic sample as the host tensors a data loader would hand over."""
     kw = {} if n_views is None else dict(n_views=n_views)
+    # points in the order a voxel-grid sampler leaves them (the first pre-transform of the
+    # reference's pipelines); MVF_BENCH_POINT_ORDER=random shuffles them instead
+    kw["order"] = os.environ.get("MVF_BENCH_POINT_ORDER", "voxel")
     sc = S.make_scene(scene, seed=seed, **kw)
     N = sc["xyz"].shape[0]
     T = torch.from_numpy
@@ -573,6 +576,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
                    + f" + max atomic pool + max/mean view pools (C={C_feat}, pools fused in one pass)",
                    "name": cfg, "points_per_gpu": N_all, "views": V, "image": [W, H],
                    "samples_per_step": n_samples,
+                   "point_order": os.environ.get("MVF_BENCH_POINT_ORDER", "voxel"),
                    "batched_pass": batched,
                    "mappings_per_sample": plan.last_counts["mappings"] // (n_samples if batched else 1),
                    "pixels_per_sample": plan.last_counts["pixels"] if splat else plan.last_counts["mappings"],

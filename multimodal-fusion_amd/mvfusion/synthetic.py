@@ -33,9 +33,12 @@ VISIBILITY_DEFAULTS = dict(
     camera="kitti360_perspective")
 
 
-def make_cloud(n_points, radius, rng):
+def make_cloud(n_points, radius, rng, order="random", voxel=0.05):
     """Surface-like cloud, float32 [n, 3]: 55 % ground disc, 30 % facade ring,
-    15 % free-standing walls (occluders) at mid radius."""
+    15 % free-standing walls (occluders) at mid radius.  ``order``: 'random'
+    (shuffled; the default, which the committed golden vectors were made with)
+    or 'voxel' (points sorted by the cell of a ``voxel``-sized grid, as after
+    grid sampling)."""
     n_ground = int(0.55 * n_points)
     n_facade = int(0.30 * n_points)
     n_wall = n_points - n_ground - n_facade
@@ -64,6 +67,13 @@ def make_cloud(n_points, radius, rng):
 
     xyz = np.concatenate([ground, facade, wall], 0)
     xyz = xyz[rng.permutation(n_points)]
+    if order == "voxel":
+        # The order a voxel-grid sampler leaves the points in: by ascending
+        # linear voxel index, x fastest (the reference's GridSampling3D, the
+        # first pre-transform of every shipped pipeline, groups the points by
+        # consecutive cluster id: core/data_transform/grid_transform.py:125-140).
+        cell = np.floor(xyz / voxel).astype(np.int64)
+        xyz = xyz[np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))]
     return xyz.astype(np.float32)
 
 
@@ -109,7 +119,7 @@ def make_scene(name=None, seed=0, **overrides):
     cfg = dict(CONFIGS[name]) if name is not None else {}
     cfg.update(overrides)
     rng = np.random.default_rng(seed)
-    xyz = make_cloud(cfg["n_points"], cfg["radius"], rng)
+    xyz = make_cloud(cfg["n_points"], cfg["radius"], rng, order=cfg.get("order", "random"))
     cams = make_cameras(cfg["n_views"], cfg["f"], cfg["cx"], cfg["cy"])
     # keep every point at least 1 cm away from every camera centre
     d = np.linalg.norm(

@@ -991,12 +991,12 @@ class DropImagesOutsideDataBoundingBox(ImageTransform):
         self.ignore_z = ignore_z
 
     def _process(self, data, images):
-        b_min = data.pos.min(dim=0).values - self.margin / 2
-        b_max = data.pos.max(dim=0).values + self.margin / 2
-        pos = images.pos.to(b_min.device)
-        mask = torch.logical_and(b_min < pos, pos < b_max)
-        mask = mask[:, 0] * mask[:, 1] if self.ignore_z else mask[:, 0] * mask[:, 1] * mask[:, 2]
-        return data, images[mask]
+        lo, hi = torch.aminmax(data.pos, dim=0)
+        pos = images.pos.to(lo.device)
+        axes = slice(0, 2) if self.ignore_z else slice(0, 3)
+        # strictly inside the box grown by margin / 2 on every side
+        inside = ((pos > lo - self.margin / 2) & (pos < hi + self.margin / 2))[:, axes].all(dim=1)
+        return data, images[inside]
 
 
 class PickKImages(ImageTransform):
@@ -1075,14 +1075,13 @@ class PickMappingsFromMappingFeatures(ImageTransform):
             return data, images
         assert max(self.feat) == 0 or max(self.feat) < m.features.shape[1], \
             f"Out of bounds feature id {max(self.feat)}."
-        features = m.features.view(m.num_items, -1)
-        view_mask = torch.ones(m.num_items, dtype=torch.bool, device=features.device)
-        for i_feat, lower, upper in zip(self.feat, self.lower, self.upper):
-            if lower is not None:
-                view_mask = view_mask & (features[:, i_feat] > lower)
-            if upper is not None:
-                view_mask = view_mask & (features[:, i_feat] < upper)
-        return data, images.select_views(view_mask)
+        # one comparison of the selected columns against [lower, upper] rows, a
+        # missing bound being infinite
+        inf = float('inf')
+        cols = m.features.view(m.num_items, -1)[:, list(self.feat)]
+        lower = cols.new_tensor([-inf if v is None else v for v in self.lower])
+        upper = cols.new_tensor([inf if v is None else v for v in self.upper])
+        return data, images.select_views(((cols > lower) & (cols < upper)).all(dim=1))
 
 
 class JitterMappingFeatures(ImageTransform):
@@ -1097,9 +1096,8 @@ class JitterMappingFeatures(ImageTransform):
         m = images.mappings
         if m is None or not m.has_features:
             return data, images
-        noise = self.sigma * torch.randn(m.features.shape)
-        noise = noise.clamp(-self.clip, self.clip)
-        m.features = m.features + noise.to(m.features.device)
+        noise = torch.randn_like(m.features).mul_(self.sigma).clamp_(-self.clip, self.clip)
+        m.features = m.features + noise
         return data, images
 
 
