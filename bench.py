@@ -677,8 +677,8 @@ def main():
         for name in ("c1", "c3", "c4", "c5"):
             torch.cuda.empty_cache()
             short = argparse.Namespace(**vars(args))
-            short.steps = 10 if name in ("c4", "c5") else max(10, min(args.steps, 30))
-            short.warmup = 3
+            short.steps = 30 if name == "c3" else 100
+            short.warmup = 5
             if name == "c3":
                 r = run_qkv(short, 0, 1, device, None, cpu_leg=False)
             else:

@@ -31,13 +31,13 @@ trace c3 --config c3 --steps 20 --warmup 3 --lanes 1
 trace c4 --config c4 --steps 5 --warmup 2
 trace c5 --config c5 --steps 10 --warmup 2 --lanes 1
 trace c2_nonexact --exact 0 --steps 5 --warmup 2 --lanes 1
-for cfg in c2 c3 c5; do
+for cfg in c2 c3 c4 c5; do
   for counter in FETCH_SIZE WRITE_SIZE; do
     pmc $cfg $counter --config $cfg --steps 3 --warmup 1
   done
 done
 cd $root
-for cfg in c2 c3 c5; do
+for cfg in c2 c3 c4 c5; do
   python3 profiles/make_traffic.py $cfg $out/${tag}_pmc_${cfg}_FETCH_SIZE $out/${tag}_pmc_${cfg}_WRITE_SIZE $out/${tag}_pmc_traffic.json > $out/${tag}_traffic_${cfg}.txt || exit 1
   rm -rf $out/${tag}_pmc_${cfg}_FETCH_SIZE $out/${tag}_pmc_${cfg}_WRITE_SIZE
 done
