@@ -434,12 +434,17 @@ def test_map_images_process_batch_equals_collated_samples():
     scenes[1]["extrinsic"] = scenes[1]["extrinsic"].copy()
     scenes[1]["extrinsic"][1, :3, 3] += 500.0
 
+    W, H = scenes[0]["img_size"]
+    mask = torch.ones((W, H), dtype=torch.bool)
+    mask[:, H - 40:] = False                       # the images share one mask (the car's bonnet, say)
+
     def inputs():
         out = []
         for k, sc in enumerate(scenes):
             n = sc["xyz"].shape[0]
             ids = np.arange(n) if k != 3 else np.random.default_rng(5).permutation(n + 300)[:n]
             out.append(make_inputs(sc["xyz"], ids, sc, sc["img_size"], attrs=True))
+            out[-1][1].mask = mask
         return [o[0] for o in out], [o[1] for o in out]
 
     t = MapImages(method="SplattingVisibility", cylinder=True, exact=True, lanes=1, **VIS)
@@ -471,7 +476,7 @@ def test_map_images_process_batch_equals_collated_samples():
         assert torch.equal(m.features, one.mappings.features), k
     # samples that cannot share a pass fall back to the loop + collation
     data, images = inputs()
-    images[2].proj_upscale = 2
+    images[2].mask = None                          # not the mask the other samples share
     assert t.prepare_batch(data, images) is None
 
 
