@@ -420,13 +420,14 @@ def test_map_images_process_batch_equals_collated_samples():
     """One batched pass over a list of cylinders (mvf_map_images_exact_batch:
     clouds and views concatenated, every point facing the views of its own
     sample) returns the batch that mapping the samples one by one and collating
-    them gives: samples of different sizes and view counts (more than 16, so
-    that the flags of a point span two chunks), one with a camera that sees
+    them gives: samples of different sizes and view counts (up to 35, so that the
+    seen flags of a point span three 16-view chunks and its kept-view mask two
+    words), one with a camera that sees
     nothing (dropped from the batch) and mapping ids that leave gaps."""
     from mvfusion.images import SameSettingImageBatch
     from mvfusion.mapping import ImageMappingBatch
     from mvfusion.transforms import MapImages
-    specs = [(30000, 8), (777, 3), (41000, 19), (20000, 5)]
+    specs = [(30000, 8), (777, 3), (41000, 35), (20000, 5)]
     scenes = [S.make_scene("c1", seed=60 + k, n_points=n, n_views=v) for k, (n, v) in enumerate(specs)]
     # a camera far away from the second sample: one unseen view
     scenes[1]["pos"] = scenes[1]["pos"].copy()
