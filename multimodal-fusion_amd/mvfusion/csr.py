@@ -68,15 +68,29 @@ class CSRData(object):
     def clone(self):
         """Shallow copy: new container, same tensors."""
         out = copy.copy(self)
-        out.pointers = copy.copy(self.pointers)
-        out.values = copy.copy(self.values)
+        out.pointers = self.pointers
+        out.values = None if self.values is None else [
+            v.clone() if isinstance(v, CSRData) else v for v in self.values]
+        return out
+
+    def _moved(self, device, non_blocking):
+        out = self.clone()
+        out.pointers = out.pointers.to(device, non_blocking=non_blocking)
+        for i in range(out.num_values):
+            v = out.values[i]
+            out.values[i] = v._moved(device, non_blocking) if isinstance(v, CSRData) \
+                else v.to(device, non_blocking=non_blocking)
         return out
 
     def to(self, device):
-        out = self.clone()
-        out.pointers = out.pointers.to(device)
-        for i in range(out.num_values):
-            out.values[i] = out.values[i].to(device)
+        """Copy on ``device``.  Device -> host copies of all arrays are queued
+        together into pinned memory and waited for once (a blocking copy per
+        array into fresh pageable memory costs several times as much)."""
+        device = torch.device(device)
+        to_host = device.type == 'cpu' and self.pointers.is_cuda
+        out = self._moved(device, to_host)
+        if to_host:
+            torch.cuda.current_stream(self.pointers.device).synchronize()
         return out
 
     def cpu(self):
@@ -190,8 +204,8 @@ class CSRBatch(CSRData):
     def num_batch_items(self):
         return len(self.__sizes__) if self.__sizes__ is not None else 0
 
-    def to(self, device):
-        out = super(CSRBatch, self).to(device)
+    def _moved(self, device, non_blocking):
+        out = super(CSRBatch, self)._moved(device, non_blocking)
         out.__sizes__ = self.__sizes__.to(device) if self.__sizes__ is not None else None
         return out
 
