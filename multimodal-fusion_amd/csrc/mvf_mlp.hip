@@ -1066,13 +1066,16 @@ static int mlp_forward_impl(
     A.vec_out = dot_out || (pool_out && !pool_max) || (((uintptr_t)out % 16 == 0) && ldo % 4 == 0 && layers[nlayers - 1].cout % 4 == 0);
     const size_t lds = mlp_lds_bytes(layers, nlayers) +
                        (pool_out ? sizeof(float) * MLP_WAVES * POOL_STAGE_ROWS * POOL_PITCH : 0);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+    // compute units of the current device (looked up once per device)
+    static int cu_cache[64];
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cu_cache[dev] == 0) {
+            hipDeviceProp_t prop;
+            cu_cache[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
+                                ? prop.multiProcessorCount : 256;
+        }
+        cus = cu_cache[dev];
     }
     i64 per_cu = (i64)(160 * 1024 / (lds + 1024));
     if (per_cu > 8) per_cu = 8;
