@@ -116,22 +116,22 @@ __device__ __forceinline__ float4 add4(const float4 &x, const float4 &y)
     return make_float4(__fadd_rn(x.x, y.x), __fadd_rn(x.y, y.y), __fadd_rn(x.z, y.z), __fadd_rn(x.w, y.w));
 }
 
-// The lane's S (a multiple of 4, at most 32) input columns c0 .. c0 + S of its
-// row as eight 16-byte loads without any branch: columns beyond S are read
+// The lane's S (a multiple of 4, at most 4 XQ <= 32) input columns c0 .. c0 + S of
+// its row as XQ 16-byte loads without any branch: columns beyond S are read
 // from c0 again and never used.  pa / pb point at the lane's row in the two
 // sources (pb = pa when there is one source); ca = columns of the first one.
-template <int MODE>
+template <int MODE, int XQ>
 __device__ __forceinline__ void mlp_load_row(
-    const float *pa, const float *pb, int ca, int c0, int S, float (&xr)[32], bool skip)
+    const float *pa, const float *pb, int ca, int c0, int S, float (&xr)[4 * XQ], bool skip)
 {
-    float4 u[8], w[8];
+    float4 u[XQ], w[XQ];
     if (skip) {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) xr[t] = 1.f;
+        for (int t = 0; t < 4 * XQ; ++t) xr[t] = 1.f;
         return;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < XQ; ++q) {
         const int c = c0 + (4 * q < S ? 4 * q : 0);
         if (MODE == 0) {
             u[q] = ld4(c < ca ? pa + c : pb + (c - ca));
@@ -145,7 +145,7 @@ __device__ __forceinline__ void mlp_load_row(
         }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < XQ; ++q) {
         float4 v = u[q];
         if (MODE == 1) v = add4(u[q], w[q]);
         if (MODE == 2) {
@@ -276,10 +276,13 @@ __device__ __forceinline__ void atomic_max_float(float *p, float v)
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
 // and LDS offsets become immediates.  NL < 0 is the general kernel that takes
 // everything from the arguments.
-template <int NL, int WMASK, int POOL>
+// XQ: 16-byte pieces of the row a lane holds for the first layer (8 = any width
+// up to 64 columns; narrow first layers take fewer registers and loads).
+template <int NL, int WMASK, int POOL, int XQ = 8>
 __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
 {
     constexpr bool FIXED = NL >= 0;
+    static_assert(FIXED || XQ == 8, "the general kernel holds whole chunks");
     const int nlayers = FIXED ? NL : A.nlayers;
     const int mode = FIXED ? 0 : A.mode;
     const bool vec_in = FIXED ? true : A.vec_in != 0;
@@ -338,7 +341,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     __syncthreads();
 
     const int cop0 = cop_of(0);
-    float xr[32];
+    float xr[4 * XQ];
     // The lane's half of a 64-column chunk of its row, 16-byte loads.  Rows past
     // the end read row 0; their results are never stored.
     // Source rows of the lane's row of the tile at base_ (row gathers applied).  Rows past
@@ -361,9 +364,9 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     auto load_rows_at = [&](i64 ra, i64 rb, int k0, int S) {
         const float *pa = A.a.p + ra * A.a.ld;
         const float *pb = A.b.p ? A.b.p + rb * A.b.ld : pa;
-        if (mode == 0) mlp_load_row<0>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
-        else if (mode == 1) mlp_load_row<1>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
-        else mlp_load_row<2>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+        if (mode == 0) mlp_load_row<0, XQ>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+        else if (mode == 1) mlp_load_row<1, XQ>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
+        else mlp_load_row<2, XQ>(pa, pb, A.a.cols, k0 + kh * S, S, xr, MLPD(A, 2));
     };
     auto load_rows = [&](i64 base_, int k0, int S) {
         int ga, gb;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                     if (live && A.a.gather) ra = A.a.gather[row];
                     if (live && A.b.gather) rb = A.b.gather[row];
 #pragma unroll
-                    for (int t = 0; t < 32; ++t) {
+                    for (int t = 0; t < 4 * XQ; ++t) {
                         xr[t] = 0.f;
                         if (live && t < S && c_lo + t < kc) xr[t] = mlp_input(A, ra, rb, k0 + c_lo + t);
                     }
@@ -453,7 +456,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             const float *wp = smem + woff[0] + c_lo * cop0 + jrow;
             if (cop0 > 32) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
+                for (int g = 0; g < XQ; ++g)
                     if (4 * g < S) {
                         float w0[4], w1[4];
 #pragma unroll
@@ -466,7 +469,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                     }
             } else {
 #pragma unroll
-                for (int g = 0; g < 8; ++g)
+                for (int g = 0; g < XQ; ++g)
                     if (4 * g < S) {
                         float w0[4];
 #pragma unroll
@@ -691,20 +694,20 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     }
 }
 
-template <int NL, int WMASK>
+template <int NL, int WMASK, int XQ = 8>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_chain_kernel(MlpArgs A)
 {
-    mlp_chain_body<NL, WMASK, 0>(A);
+    mlp_chain_body<NL, WMASK, 0, XQ>(A);
 }
 
 // The pool epilogue's staging rows leave LDS for three workgroups per CU; the register
 // budget is held to the same three waves per SIMD (the scheduler otherwise spends registers
 // on early weight reads and drops to two).
-template <int NL, int WMASK, int POOL>
+template <int NL, int WMASK, int POOL, int XQ = 8>
 __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(3)))
 void mlp_chain_pool_kernel(MlpArgs A)
 {
-    mlp_chain_body<NL, WMASK, POOL>(A);
+    mlp_chain_body<NL, WMASK, POOL, XQ>(A);
 }
 
 // ------------------------------------------------------------------------- //
@@ -1087,18 +1090,36 @@ static int mlp_forward_impl(
     int wmask = 0;
     for (int l = 0; l < nlayers; ++l) wmask |= (layers[l].cout > 32 ? 1 : 0) << l;
     const bool fixed = A.vec_in && A.vec_out && mode == 0;
+    // 16-byte pieces of the first layer's row per lane: half of the columns (one k-half)
+    const int need = (((cin0 + 1) >> 1) + 3) / 4;
+    const int xq = cin0 > MLP_KC ? 8 : need <= 1 ? 1 : need <= 4 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
-#define MVF_MLP_LAUNCH(NL_, WM_)                                                                 \
+#define MVF_MLP_LAUNCH_X(NL_, WM_, XQ_)                                                          \
     do {                                                                                         \
-        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_>,                    \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, XQ_>,               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_>), grid, dim3(MLP_THREADS), lds, st, A);   \
+        hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, XQ_>), grid, dim3(MLP_THREADS), lds, st, A); \
+    } while (0)
+#define MVF_MLP_LAUNCH(NL_, WM_) MVF_MLP_LAUNCH_X(NL_, WM_, 8)
+    // chains of narrow layers also come with the first layer's row held in 1 or 4
+    // 16-byte pieces per lane (8 / 32 input columns) instead of 8
+#define MVF_MLP_LAUNCH_NARROW(NL_)                                                               \
+    do {                                                                                         \
+        if (xq == 1) MVF_MLP_LAUNCH_X(NL_, 0, 1);                                                \
+        else if (xq == 4) MVF_MLP_LAUNCH_X(NL_, 0, 4);                                           \
+        else MVF_MLP_LAUNCH_X(NL_, 0, 8);                                                        \
+    } while (0)
+#define MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, XQ_)                                                 \
+    do {                                                                                         \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_pool_kernel<NL_, WM_, P_, XQ_>,      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL((mlp_chain_pool_kernel<NL_, WM_, P_, XQ_>), grid, dim3(MLP_THREADS), lds, st, A); \
     } while (0)
 #define MVF_MLP_LAUNCH_POOL(NL_, WM_, P_)                                                        \
     do {                                                                                         \
-        MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_pool_kernel<NL_, WM_, P_>,                \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL((mlp_chain_pool_kernel<NL_, WM_, P_>), grid, dim3(MLP_THREADS), lds, st, A); \
+        if ((WM_) == 0 && xq == 1) MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 1);                       \
+        else if ((WM_) == 0 && xq == 4) MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 4);                  \
+        else MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 8);                                             \
     } while (0)
     if (pool_out) {
         MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
@@ -1115,13 +1136,13 @@ static int mlp_forward_impl(
         }
     } else if (!fixed) MVF_MLP_LAUNCH(-1, 0);
     else switch (nlayers * 8 + wmask) {
-    case 8 + 0: MVF_MLP_LAUNCH(1, 0); break;
+    case 8 + 0: MVF_MLP_LAUNCH_NARROW(1); break;
     case 8 + 1: MVF_MLP_LAUNCH(1, 1); break;
-    case 16 + 0: MVF_MLP_LAUNCH(2, 0); break;
+    case 16 + 0: MVF_MLP_LAUNCH_NARROW(2); break;
     case 16 + 1: MVF_MLP_LAUNCH(2, 1); break;
     case 16 + 2: MVF_MLP_LAUNCH(2, 2); break;
     case 16 + 3: MVF_MLP_LAUNCH(2, 3); break;
-    case 24 + 0: MVF_MLP_LAUNCH(3, 0); break;
+    case 24 + 0: MVF_MLP_LAUNCH_NARROW(3); break;
     case 24 + 1: MVF_MLP_LAUNCH(3, 1); break;
     case 24 + 2: MVF_MLP_LAUNCH(3, 2); break;
     case 24 + 3: MVF_MLP_LAUNCH(3, 3); break;
@@ -1131,7 +1152,10 @@ static int mlp_forward_impl(
     default: MVF_MLP_LAUNCH(3, 7); break;
     }
 #undef MVF_MLP_LAUNCH
+#undef MVF_MLP_LAUNCH_X
+#undef MVF_MLP_LAUNCH_NARROW
 #undef MVF_MLP_LAUNCH_POOL
+#undef MVF_MLP_LAUNCH_POOL_X
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
