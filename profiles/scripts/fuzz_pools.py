@@ -12,7 +12,8 @@ import torch
 
 import mvf_oracle as orc
 from mvfusion import mapping as M
-from mvfusion.pooling import gather_csr, segment_csr, segment_csr_two_level, segment_softmax_csr
+from mvfusion.pooling import (gather_atomic_pool, gather_csr, gather_features, segment_csr,
+                              segment_csr_two_level, segment_softmax_csr, sparse_interpolation)
 
 DEV = "cuda"
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
@@ -40,7 +41,33 @@ def close(got, want, exact):
 
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    what = rng.choice(["segment", "segment", "two_level", "softmax", "gather", "dense", "select"])
+    what = rng.choice(["segment", "segment", "two_level", "softmax", "gather", "dense", "select",
+                       "feature_maps", "interpolation"])
+    if what in ("feature_maps", "interpolation"):
+        B, C_ = int(rng.integers(1, 9)), int(rng.choice([1, 3, 13, 32, 70]))
+        H, W = int(rng.integers(2, 90)), int(rng.integers(2, 120))
+        x = rng.normal(size=(B, C_, H, W)).astype(np.float32)
+        desc = f"seed {seed} {what} B={B} C={C_} {W}x{H}"
+        if what == "interpolation":
+            n = int(rng.integers(1, 20000))
+            coords = rng.uniform(0.0, 1.0, (n, 2)).astype(np.float32)      # the reference asserts [0, 1]
+            coords[rng.random(n) < 0.1] = rng.choice([0.0, 1.0, 0.5])
+            batch = rng.integers(0, B, n)
+            pad = str(rng.choice(["border", "zeros", "reflection"]))
+            got = N(sparse_interpolation(T(x), T(coords), T(batch), padding_mode=pad))
+            close(got, orc.sparse_interpolation(x, coords, batch, pad), True)
+            return desc + f" n={n} {pad}"
+        n_views = int(rng.integers(1, 5000))
+        vptr = random_ptr(rng, n_views, "short")
+        images = rng.integers(0, B, n_views)
+        pix = np.stack([rng.integers(0, W, int(vptr[-1])), rng.integers(0, H, int(vptr[-1]))], 1).astype(np.int16)
+        m = M.ImageMapping.from_csr_arrays(T(np.arange(n_views + 1, dtype=np.int64)), T(images), T(pix), None,
+                                           view_pointers=T(vptr))
+        dense = orc.gather_features(x, images, vptr, pix)
+        assert np.array_equal(N(gather_features(T(x), m)), dense)
+        mode = str(rng.choice(["max", "min", "mean", "sum"]))
+        close(N(gather_atomic_pool(T(x), m, mode)), orc.segment_csr(dense, vptr, mode), mode in ("max", "min"))
+        return desc + f" views={n_views} {mode}"
     if what in ("segment", "two_level", "softmax", "gather"):
         nseg = int(rng.integers(1, 4000))
         kind = str(rng.choice(["short", "long", "mixed"]))
@@ -134,7 +161,10 @@ if __name__ == "__main__":
         try:
             print("ok |", one_case(seed), flush=True)
         except Exception as e:          # report and go on: the sweep lists every failing seed
+            import traceback
             bad += 1
-            print("FAIL", seed, type(e).__name__, str(e)[:300].replace("\n", " "), flush=True)
+            where = traceback.extract_tb(e.__traceback__)[-1]
+            print("FAIL", seed, type(e).__name__, f"line {where.lineno}: {where.line}",
+                  str(e)[:300].replace("\n", " "), flush=True)
     print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
