@@ -2,7 +2,8 @@
 oracle: random scene sizes, view counts, image sizes that are no multiple of the tile size,
 crops, masks, scale factors, sampling radii, swell parameters, exact / plain splat visibility,
 depth-map visibility, mapping ids with gaps, point attributes on / off.
-usage (GPU box, repo root): python profiles/scripts/fuzz_parity.py [cases] [first seed]"""
+A third argument "wide" draws fisheye / equirectangular cameras instead (per-view path).
+usage (GPU box, repo root): python profiles/scripts/fuzz_parity.py [cases] [first seed] [wide]"""
 import sys
 import time
 
@@ -22,9 +23,65 @@ from test_gpu_parity import Data, check_mapping
 T = torch.from_numpy
 
 
+WIDE_ONLY = False
+FISHEYE = np.array([2.2134, 0.016, 0.4325, 1336.3, 1335.8, 716.9, 705.8], np.float32)
+
+
+def wide_case(seed, rng):
+    """MapImages with fisheye / equirectangular images (view by view on the device)."""
+    cam = str(rng.choice(["kitti360_fisheye", "s3dis_equirectangular"]))
+    n_points, n_views = int(rng.integers(500, 40000)), int(rng.integers(1, 7))
+    sc = S.make_scene("c1", seed=seed, n_points=n_points, n_views=n_views,
+                      radius=float(rng.uniform(3, 20)))
+    cams = dict(pos=sc["pos"])
+    if cam == "kitti360_fisheye":
+        side = int(rng.integers(300, 1500)) // 2 * 2
+        size = (side, side)
+        fe = FISHEYE.copy()
+        fe[3:] *= side / 1400.0
+        fe[:3] *= np.float32(rng.uniform(0.9, 1.1))
+        cams["extrinsic"] = sc["extrinsic"]
+        cams["fisheye"] = np.tile(fe, (n_views, 1)).astype(np.float32)
+    else:
+        h = int(rng.integers(100, 600)) // 2 * 2
+        size = (2 * h, h)
+        yaw = rng.uniform(0, 2 * np.pi, n_views)
+        cams["opk"] = np.stack([rng.uniform(-0.1, 0.1, n_views), rng.uniform(-0.1, 0.1, n_views), yaw],
+                               1).astype(np.float32)
+    up = int(rng.choice([1, 2]))
+    ref_size = (size[0] // up, size[1] // up)
+    exact = bool(rng.random() < 0.6)
+    cylinder = bool(rng.random() < 0.7)
+    vis = dict(r_max=float(rng.uniform(4, 25)), r_min=float(rng.choice([0, 0.5])), camera=cam, exact=exact,
+               voxel=float(rng.choice([0.05, 0.1])), k_swell=float(rng.uniform(0.5, 2)), d_swell=1e6)
+    desc = f"seed {seed} wide {cam} N={n_points} V={n_views} {size} up={up} exact={exact} cyl={cylinder}"
+    N = sc["xyz"].shape[0]
+    data = Data()
+    data.pos = T(sc["xyz"])
+    data.mapping_index = torch.arange(N)
+    if "fisheye" in cams:
+        f = T(cams["fisheye"])
+        extra = dict(extrinsic=T(cams["extrinsic"]), xi=f[:, 0], k1=f[:, 1], k2=f[:, 2],
+                     gamma1=f[:, 3], gamma2=f[:, 4], u0=f[:, 5], v0=f[:, 6])
+    else:
+        extra = dict(opk=T(cams["opk"]))
+    images = SameSettingImageData(pos=T(cams["pos"]), ref_size=ref_size, proj_upscale=up, **extra)
+    t = MapImages(method="SplattingVisibility", cylinder=cylinder, point_order="index", **vis)
+    try:
+        _, out = t(data, images)
+    except ValueError as e:
+        return desc, "no mapping (%s)" % str(e)[:30]
+    ref = orc.map_images(sc["xyz"], np.arange(N), cams, order=None, ref_size=ref_size, proj_upscale=up,
+                         cylinder=cylinder, **vis)
+    check_mapping(out.mappings, ref)
+    return desc, "ok %d rows %d pixels" % (ref["images"].shape[0], ref["pixels"].shape[0])
+
+
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    mode = rng.choice(["exact", "exact", "exact", "splat", "depth", "batch"])
+    mode = rng.choice(["exact", "exact", "exact", "splat", "depth", "batch"] if not WIDE_ONLY else ["wide"])
+    if mode == "wide":
+        return wide_case(seed, rng)
     W = int(rng.integers(90, 700))
     H = int(rng.integers(70, 500))
     n_views = int(rng.integers(1, 40 if mode != "splat" else 8))
@@ -140,6 +197,7 @@ def one_case(seed):
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    WIDE_ONLY = len(sys.argv) > 3 and sys.argv[3] == "wide"
     bad = 0
     t0 = time.time()
     for seed in range(first, first + cases):
