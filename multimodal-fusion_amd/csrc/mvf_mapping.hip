@@ -61,13 +61,16 @@ struct ArraySrc {                      // visibility_from_splatting(x_proj, y_pr
     }
 };
 
-struct CloudSrc {                      // fused MapImages: project xyz[i] into view v
+// fused MapImages: project xyz[i] into view v.  ANY_ = false: pinhole cameras
+// only (no trace of the other camera models in the kernels); true: any camera.
+template <bool ANY_>
+struct CloudSrcT {
     const float *xyz; const mvf_view *views; const uint8_t *mask; i64 n; int cylinder;
     // Batch of samples in one call: window[i] = {first view, number of views} of
     // point position i (the views of its own sample); null = every point meets
     // all V views.  Kernels walk a point's views by their index inside the window.
     const int2 *window;
-    static constexpr bool ANY = false;     // pinhole cameras only
+    static constexpr bool ANY = ANY_;
     __device__ i64 count() const { return n; }
     __device__ int2 views_of(i64 i, int V) const { return window ? window[i] : make_int2(0, V); }
     __device__ bool get(i64 i, int v, const mvf_vis_params &P, double &ox, double &oy, float &od,
@@ -75,7 +78,7 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
         const float px = xyz[3 * i], py = xyz[3 * i + 1], pz = xyz[3 * i + 2];
         const mvf_view &view = views[v];
         Proj pr;
-        if (!project_point<false>(px, py, pz, view, P, mask, pr)) return false;
+        if (!project_point<ANY_>(px, py, pz, view, P, mask, pr)) return false;
         // radius sampling of MapImages (image.py:242-245; transforms.py:332,386):
         // float64 squared distance to the view centre <= r_max^2 (tested last: it
         // only removes points, and few reach it)
@@ -83,10 +86,14 @@ struct CloudSrc {                      // fused MapImages: project xyz[i] into v
         double d2 = ex * ex + ey * ey;
         if (!cylinder) { const double ez = (double)pz - view.centre[2]; d2 = d2 + ez * ez; }
         if (!(d2 <= P.r_max * P.r_max)) return false;
-        ox = pr.x; oy = pr.y; od = pr.dist; sx = (double)view.fx; sy = (double)view.fy;
+        ox = pr.x; oy = pr.y; od = pr.dist;
+        if (ANY_ && P.camera == MVF_CAM_KITTI360_FISHEYE) sx = sy = fisheye_splat_width(px, py, pz, ox, oy, view, P);
+        else { sx = (double)view.fx; sy = (double)view.fy; }
         return true;
     }
 };
+using CloudSrc = CloudSrcT<false>;
+using CloudSrcAny = CloudSrcT<true>;
 
 // ------------------------------------------------------------------------- //
 // binning: count, fill                                                        //
@@ -1029,7 +1036,8 @@ __device__ __forceinline__ unsigned seen_chunk(const uint8_t *seen, i64 seen_str
 // Copies the views of a call into LDS (16 bytes per thread step) and returns the
 // source with its view table there: the per-lane, per-view camera constants of
 // the kernels below are then LDS reads instead of divergent global loads.
-__device__ __forceinline__ CloudSrc views_to_lds(CloudSrc src, int V, mvf_view *lds_views)
+template <class Src>
+__device__ __forceinline__ Src views_to_lds(Src src, int V, mvf_view *lds_views)
 {
     const uint4 *g = (const uint4 *)src.views;
     uint4 *l = (uint4 *)lds_views;
@@ -1039,8 +1047,9 @@ __device__ __forceinline__ CloudSrc views_to_lds(CloudSrc src, int V, mvf_view *
     return src;
 }
 
+template <class Src>
 __global__ __launch_bounds__(256) void mi_centre_kernel(
-    CloudSrc src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int V, int Hc,
+    Src src, mvf_vis_params P, const uint8_t *__restrict__ seen, i64 seen_stride, int V, int Hc,
     CentreTable table, i64 *__restrict__ overflow)
 {
     extern __shared__ __align__(16) unsigned char dyn_lds[];
@@ -1101,9 +1110,9 @@ struct DepthKeep {
 // mapping in view v, and at which (converted) pixel?  0 = not mapped, 1 =
 // mapped by the visibility model but outside the crop (the view still counts
 // as seen, image.py:289-290,350), 2 = kept.
-template <class Keep>
+template <class Keep, class Src>
 __device__ __forceinline__ int mi_survives(
-    const CloudSrc &src, const mvf_vis_params &P, const Keep &keep, const PixelXform &X, i64 i, int v,
+    const Src &src, const mvf_vis_params &P, const Keep &keep, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
     double x, y, fx, fy;
@@ -1121,8 +1130,9 @@ __device__ __forceinline__ int mi_survives(
 
 // Pixel, distance and y_proj of a kept (point, view) mapping (no visibility
 // re-check: the caller holds the kept-view mask).
+template <class Src>
 __device__ __forceinline__ void mi_pixel(
-    const CloudSrc &src, const mvf_vis_params &P, const PixelXform &X, i64 i, int v,
+    const Src &src, const mvf_vis_params &P, const PixelXform &X, i64 i, int v,
     int &px, int &py, float &dist, double &y_proj)
 {
     double x, y, fx, fy;
@@ -1135,9 +1145,9 @@ __device__ __forceinline__ void mi_pixel(
 // Pass 1 of the CSR assembly: one thread per output point id.  Tests the
 // candidate views of its point (projection, visibility model, crop), stores
 // the kept-view bit masks masks[word][q] and the block's mapping count.
-template <class Keep>
+template <class Keep, class Src>
 __global__ __launch_bounds__(256) void mi_point_mask_kernel(
-    CloudSrc src, mvf_vis_params P, Keep keep, PixelXform X, int V, int Vw,
+    Src src, mvf_vis_params P, Keep keep, PixelXform X, int V, int Vw,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_sums, int *__restrict__ view_seen)
 {
@@ -1172,8 +1182,9 @@ __global__ __launch_bounds__(256) void mi_point_mask_kernel(
 // ascending inside a point.  Every block adds up the counts of the blocks in
 // front of it itself, and ranks the seen views among the seen views (lexunique
 // + bucketize, image.py:392-394) in LDS; the last block also stores the totals.
+template <class Src>
 __global__ __launch_bounds__(256) void mi_fill_kernel(
-    CloudSrc src, mvf_vis_params P, PixelXform X, int V, int Vw, const i64 *__restrict__ inv_ids,
+    Src src, mvf_vis_params P, PixelXform X, int V, int Vw, const i64 *__restrict__ inv_ids,
     i64 num_points, const unsigned *__restrict__ masks, const unsigned *__restrict__ block_sums,
     const int *__restrict__ view_seen, FeatArgs A, i64 out_capacity,
     i64 *__restrict__ pointers, i64 *__restrict__ images, int16_t *__restrict__ pixels,
@@ -1427,8 +1438,9 @@ __device__ __forceinline__ float repeat_add(float f, unsigned c)
 // Pointers, images, view pointers and view features (mean over the view's
 // pixels, which all carry the features of the point, summed one by one as a
 // segment mean does); poff[i][v] <- first pixel of the pair for the pixel pass.
+template <class Src>
 __global__ __launch_bounds__(256) void ne_fill_kernel(
-    CloudSrc src, mvf_vis_params P, int V, const i64 *__restrict__ inv_ids, i64 num_points,
+    Src src, mvf_vis_params P, int V, const i64 *__restrict__ inv_ids, i64 num_points,
     const unsigned *__restrict__ masks, const unsigned *__restrict__ block_rows,
     const i64 *__restrict__ block_pix, const unsigned *__restrict__ cnt, const int *__restrict__ view_seen,
     FeatArgs A, i64 out_capacity, i64 pix_capacity, i64 *__restrict__ pointers, i64 *__restrict__ images,
@@ -1913,6 +1925,7 @@ extern "C" int mvf_profile_zbuffer_ops(
 
 // The fused exact pass.  window / view_first / Vw describe a batch of samples
 // (null, null, V: one sample whose points meet all V views).
+template <class Src>
 static int map_images_exact_impl(
     const float *xyz, const int64_t *inv_ids, int64_t n,
     int64_t num_points, const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
@@ -1935,8 +1948,6 @@ static int map_images_exact_impl(
     MVF_REQUIRE(h_params->exact, "map_images_exact: params.exact must be set");
     MVF_REQUIRE((double)V * h_params->W * h_params->H < 4294967295.0,
                 "map_images_exact: V * W * H = %d * %d * %d does not fit 32 bits", V, h_params->W, h_params->H);
-    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
-                "map_images_exact: pinhole cameras only");
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     int tiles_x, tiles_y, Hc;
@@ -1962,14 +1973,14 @@ static int map_images_exact_impl(
     MVF_HIP(hipMemsetAsync(tile_count, 0, clear_bytes, st));
     prof_mark("memset", st);
 
-    CloudSrc src{xyz, views, mask, (i64)n, cylinder, window};
+    Src src{xyz, views, mask, (i64)n, cylinder, window};
     dim3 grid_nv(cdiv(n, 256), Vw), block(256);
     if (window)
-        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS, true>), grid_nv, block, 0, st, src, P, tiles_y,
+        hipLaunchKernelGGL((bin_count_kernel<Src, true, BIN_LDS, true>), grid_nv, block, 0, st, src, P, tiles_y,
                            tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
                            staged_count);
     else
-        hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
+        hipLaunchKernelGGL((bin_count_kernel<Src, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
                            tiles_per_view, tile_count, seen, seen_stride, (i64 *)counters, view_seen, V, staged,
                            staged_count);
     prof_mark("bin_count", st);
@@ -1987,17 +1998,17 @@ static int map_images_exact_impl(
                        descs, tile_count + ncnt, tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity, tiles_y, tiles_per_view, P.W, Hc,
                        seen, seen_stride, (unsigned *)nullptr, view_first);
     prof_mark("tile_zbuffer", st);
-    hipLaunchKernelGGL(mi_centre_kernel, dim3(cdiv(n, 256)), block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, V, Hc,
+    hipLaunchKernelGGL((mi_centre_kernel<Src>), dim3(cdiv(n, 256)), block, (size_t)V * sizeof(mvf_view), st, src, P, seen, seen_stride, V, Hc,
                        table, (i64 *)counters + 2);
     prof_mark("centre", st);
 
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb);
-    hipLaunchKernelGGL((mi_point_mask_kernel<SplatKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
+    hipLaunchKernelGGL((mi_point_mask_kernel<SplatKeep, Src>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
                        SplatKeep{seen, seen_stride, table, Hc}, X, V, Vw, (const i64 *)inv_ids, (i64)num_points,
                        masks, block_sums, view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, Vw,
+    hipLaunchKernelGGL((mi_fill_kernel<Src>), grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, Vw,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
@@ -2017,7 +2028,13 @@ extern "C" int mvf_map_images_exact(
     int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
 {
     (void)point_ids;
-    return map_images_exact_impl(
+    if (h_params && h_params->camera >= MVF_CAM_KITTI360_FISHEYE)
+        return map_images_exact_impl<CloudSrcAny>(
+            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
+            normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
+            pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
+            (const int2 *)nullptr, (const int *)nullptr, V);
+    return map_images_exact_impl<CloudSrc>(
         xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
         normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
         pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
@@ -2048,7 +2065,13 @@ extern "C" int mvf_map_images_exact_batch(
     int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
 {
     MVF_REQUIRE(view_window && view_first, "map_images_exact_batch: null view window");
-    return map_images_exact_impl(
+    if (h_params && h_params->camera >= MVF_CAM_KITTI360_FISHEYE)
+        return map_images_exact_impl<CloudSrcAny>(
+            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
+            normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
+            pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
+            (const int2 *)view_window, (const int *)view_first, views_per_point);
+    return map_images_exact_impl<CloudSrc>(
         xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering,
         normals, proj_upscale, downscale, crop_w, crop_h, centre_slots, pair_capacity, pointers, images,
         pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream,
@@ -2066,7 +2089,8 @@ extern "C" size_t mvf_map_images_depth_workspace_bytes(int64_t num_points, int32
            align_up(nb * sizeof(unsigned));
 }
 
-extern "C" int mvf_map_images_depth(
+template <class Src>
+static int map_images_depth_impl(
     const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
     int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
     const float *depth_maps, const float *linearity, const float *planarity, const float *scattering,
@@ -2081,8 +2105,6 @@ extern "C" int mvf_map_images_depth(
                 view_seen && counters, "map_images_depth: null buffer");
     MVF_REQUIRE(proj_upscale >= 1 && downscale >= 1 && crop_w >= 1 && crop_h >= 1 && out_capacity >= 0,
                 "map_images_depth: bad scalar argument");
-    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
-                "map_images_depth: pinhole cameras only");
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     const i64 nb = cdiv(num_points, 256);
@@ -2096,14 +2118,14 @@ extern "C" int mvf_map_images_depth(
     MVF_HIP(hipMemsetAsync(counters, 0, 8 * sizeof(int64_t), st));
     MVF_HIP(hipMemsetAsync(view_seen, 0, (size_t)V * sizeof(int32_t), st));
     prof_mark("memset", st);
-    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
+    Src src{xyz, views, mask, (i64)n, cylinder};
     PixelXform X{proj_upscale, downscale, crop_w, crop_h};
     dim3 grid_q((unsigned)nb), block(256);
-    hipLaunchKernelGGL((mi_point_mask_kernel<DepthKeep>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
+    hipLaunchKernelGGL((mi_point_mask_kernel<DepthKeep, Src>), grid_q, block, (size_t)V * sizeof(mvf_view), st, src, P,
                        DepthKeep{depth_maps}, X, V, V, (const i64 *)inv_ids, (i64)num_points, masks, block_sums,
                        view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(mi_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, V,
+    hipLaunchKernelGGL((mi_fill_kernel<Src>), grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st, src, P, X, V, V,
                        (const i64 *)inv_ids, (i64)num_points, masks, block_sums, view_seen,
                        feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64 *)pointers, (i64 *)images, pixels, features,
@@ -2111,6 +2133,21 @@ extern "C" int mvf_map_images_depth(
     prof_mark("csr_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_map_images_depth(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
+    int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *depth_maps, const float *linearity, const float *planarity, const float *scattering,
+    const float *normals, int32_t proj_upscale, int32_t downscale, int32_t crop_w, int32_t crop_h,
+    int64_t *pointers, int64_t *images, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t *view_seen, int64_t *counters, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (h_params && h_params->camera >= MVF_CAM_KITTI360_FISHEYE)
+        return map_images_depth_impl<CloudSrcAny>(
+            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, depth_maps, linearity, planarity, scattering, normals, proj_upscale, downscale, crop_w, crop_h, pointers, images, pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream);
+    return map_images_depth_impl<CloudSrc>(
+        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, depth_maps, linearity, planarity, scattering, normals, proj_upscale, downscale, crop_w, crop_h, pointers, images, pixels, features, out_capacity, view_seen, counters, workspace, workspace_bytes, stream);
 }
 
 // MapImages with SplattingVisibility(exact=False), all views in one launch set:
@@ -2126,7 +2163,8 @@ extern "C" size_t mvf_map_images_splat_workspace_bytes(
     return ws.used;
 }
 
-extern "C" int mvf_map_images_splat(
+template <class Src>
+static int map_images_splat_impl(
     const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
     int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
     const float *linearity, const float *planarity, const float *scattering, const float *normals,
@@ -2142,8 +2180,6 @@ extern "C" int mvf_map_images_splat(
                 view_seen && counters, "map_images_splat: null buffer");
     MVF_REQUIRE(crop_w >= 1 && crop_h >= 1 && pair_capacity >= 1 && out_capacity >= 0 && pix_capacity >= 0,
                 "map_images_splat: bad scalar argument");
-    MVF_REQUIRE(h_params->camera == MVF_CAM_KITTI360_PERSPECTIVE || h_params->camera == MVF_CAM_SCANNET,
-                "map_images_splat: pinhole cameras only");
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     int tiles_x, tiles_y, Hc;
@@ -2161,9 +2197,9 @@ extern "C" int mvf_map_images_splat(
     prof_begin(st);
     MVF_HIP(hipMemsetAsync(ws.tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
     prof_mark("memset", st);
-    CloudSrc src{xyz, views, mask, (i64)n, cylinder};
+    Src src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
-    hipLaunchKernelGGL((bin_count_kernel<CloudSrc, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
+    hipLaunchKernelGGL((bin_count_kernel<Src, true, BIN_LDS>), grid_nv, block, 0, st, src, P, tiles_y,
                        tiles_per_view, ws.tile_count, ws.seen, ws.seen_stride, (i64 *)counters, view_seen, V,
                        ws.staged, ws.staged_count);
     prof_mark("bin_count", st);
@@ -2187,7 +2223,7 @@ extern "C" int mvf_map_images_splat(
     hipLaunchKernelGGL(ne_point_kernel, grid_q, block, 0, st, ws.seen, ws.seen_stride, ws.cnt, V,
                        (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix, view_seen);
     prof_mark("point_mask", st);
-    hipLaunchKernelGGL(ne_fill_kernel, grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st,
+    hipLaunchKernelGGL((ne_fill_kernel<Src>), grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st,
                        src, P, V, (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix,
                        ws.cnt, view_seen, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64)pix_capacity, (i64 *)pointers, (i64 *)images, (i64 *)view_pointers,
@@ -2199,4 +2235,20 @@ extern "C" int mvf_map_images_splat(
     prof_mark("pixel_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_map_images_splat(
+    const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
+    int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
+    const float *linearity, const float *planarity, const float *scattering, const float *normals,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers, int64_t *images,
+    int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
+    int64_t pix_capacity, int32_t *view_seen, int64_t *counters, void *workspace,
+    size_t workspace_bytes, void *stream)
+{
+    if (h_params && h_params->camera >= MVF_CAM_KITTI360_FISHEYE)
+        return map_images_splat_impl<CloudSrcAny>(
+            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
+    return map_images_splat_impl<CloudSrc>(
+        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
 }

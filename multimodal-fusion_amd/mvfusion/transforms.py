@@ -94,10 +94,23 @@ _VIEW_DTYPE = np.dtype({
 
 
 def pack_views(images, camera):
-    """[V] mvf_view structs of pinhole views as a host uint8 tensor (the layout
-    of ``_lib.MvfView``; what ``visibility.make_view`` fills for one view)."""
-    assert camera in ('kitti360_perspective', 'scannet')
+    """[V] mvf_view structs of the views as a host uint8 tensor (the layout of
+    ``_lib.MvfView``; what ``visibility.make_view`` fills for one view)."""
     V = images.num_views
+    if camera in ('kitti360_fisheye', 's3dis_equirectangular'):
+        # few views, many camera parameters: one make_view per view
+        fish = images.intrinsic_fisheye.float() if getattr(images, 'is_fisheye', False) else None
+        opk = images.opk.float() if getattr(images, 'has_opk', False) else None
+        parts = []
+        for v in range(V):
+            view = visibility_module.make_view(
+                images.pos[v], None, images.extrinsic[v].float() if images.has_extrinsic else None, camera,
+                centre=images.pos[v].double(), crop_offsets=images.crop_offsets[v].tolist(),
+                img_opk=None if opk is None else opk[v],
+                img_intrinsic_fisheye=None if fish is None else fish[v])
+            parts.append(np.frombuffer(bytes(view), dtype=np.uint8))
+        return torch.from_numpy(np.concatenate(parts).copy())
+    assert camera in ('kitti360_perspective', 'scannet')
     arr = np.zeros(V, dtype=_VIEW_DTYPE)
     pos = np.asarray(images.pos.detach().cpu())
     arr['img_xyz'] = pos.astype(np.float32)
@@ -446,12 +459,14 @@ class MapImages(ImageTransform):
         """Can all views of these images go through one launch set?  Splat
         visibility (exact, or plain at the images' own resolution) or depth-map
         visibility (with the decoded maps at hand as ``images.depth_maps``),
-        pinhole cameras, integer scale factors."""
+        integer scale factors, any of the four cameras."""
         ints = all(float(s).is_integer() and s >= 1
                    for s in (images.proj_upscale, images.downscale))
-        common = (visi_model.camera in ('kitti360_perspective', 'scannet')
-                  and ints and images.pixel_dtype == torch.int16
-                  and images.is_pinhole and images.has_extrinsic
+        if visi_model.camera in ('kitti360_perspective', 'scannet'):
+            camera_ok = images.is_pinhole and images.has_extrinsic
+        else:
+            camera_ok = visi_model.camera in ('kitti360_fisheye', 's3dis_equirectangular')
+        common = (camera_ok and ints and images.pixel_dtype == torch.int16
                   and images.num_views <= 480)
         if self.method == 'SplattingVisibility':
             small = images.num_views * images.proj_size[0] * images.proj_size[1] < 2 ** 32 - 1
@@ -709,7 +724,8 @@ class MapImages(ImageTransform):
         """The packed views on the device, kept on ``images`` for the next call on
         the same, unmodified camera tensors."""
         src = [images.pos, images.extrinsic, images.crop_offsets] + [
-            getattr(images, k) for k in ('fx', 'fy', 'mx', 'my')]
+            getattr(images, k, None) for k in ('fx', 'fy', 'mx', 'my', 'opk', 'xi', 'k1', 'k2',
+                                                'gamma1', 'gamma2', 'u0', 'v0')]
         key = (str(device), camera) + tuple(
             (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else repr(t) for t in src)
         cached = getattr(images, '_mvf_views', None)

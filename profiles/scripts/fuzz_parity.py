@@ -66,7 +66,44 @@ def wide_case(seed, rng):
     else:
         extra = dict(opk=T(cams["opk"]))
     images = SameSettingImageData(pos=T(cams["pos"]), ref_size=ref_size, proj_upscale=up, **extra)
+    if rng.random() < 0.25 and up == 1:
+        # depth-map visibility on maps rendered from the cloud itself
+        dv = {k: vis[k] for k in ("r_max", "r_min", "camera")}
+        thr = float(rng.choice([0.05, 0.2]))
+        kw = {k: vis[k] for k in ("voxel", "k_swell", "d_swell", "r_max", "r_min")}
+        maps = []
+        for v in range(n_views):
+            mk = {}
+            if "extrinsic" in cams:
+                mk["img_extrinsic"] = cams["extrinsic"][v]
+            if "fisheye" in cams:
+                mk["img_intrinsic_fisheye"] = cams["fisheye"][v]
+            if "opk" in cams:
+                mk["img_opk"] = cams["opk"][v]
+            img_xyz = cams["pos"][v].astype(np.float32)
+            i1, dist, x, y = orc.camera_projection(sc["xyz"], img_xyz, img_size=size, camera=cam,
+                                                   r_max=vis["r_max"], r_min=vis["r_min"], **mk)
+            dm = np.full(size, -1.0, np.float32)
+            if i1.shape[0]:
+                i2, xp, yp = orc.visibility_from_splatting(
+                    x, y, dist, sc["xyz"][i1], exact=False, img_size=size, camera=cam,
+                    voxel=vis["voxel"], k_swell=vis["k_swell"], d_swell=vis["d_swell"], **mk)
+                dm[xp, yp] = np.round(dist[i2] * np.float32(512)) / np.float32(512)
+            maps.append(dm)
+        images.depth_maps = [T(m).cuda() for m in maps]
+        t = MapImages(method="DepthBasedVisibility", cylinder=cylinder, point_order="index",
+                      depth_threshold=thr, **dv)
+        assert t._fusable(images, t._settle(data, images))
+        try:
+            _, out = t(data, images)
+        except ValueError as e:
+            return desc, "no mapping (%s)" % str(e)[:30]
+        ref = orc.map_images(sc["xyz"], np.arange(N), cams, order=None, ref_size=ref_size, cylinder=cylinder,
+                             method="depth_map", depth_maps=maps, depth_threshold=thr, **dv)
+        check_mapping(out.mappings, ref)
+        return desc + " depth", "ok %d mappings" % ref["images"].shape[0]
     t = MapImages(method="SplattingVisibility", cylinder=cylinder, point_order="index", **vis)
+    fused = t._fusable(images, t._settle(data, images))
     try:
         _, out = t(data, images)
     except ValueError as e:
@@ -74,7 +111,8 @@ def wide_case(seed, rng):
     ref = orc.map_images(sc["xyz"], np.arange(N), cams, order=None, ref_size=ref_size, proj_upscale=up,
                          cylinder=cylinder, **vis)
     check_mapping(out.mappings, ref)
-    return desc, "ok %d rows %d pixels" % (ref["images"].shape[0], ref["pixels"].shape[0])
+    return desc + (" fused" if fused else " per-view"), \
+        "ok %d rows %d pixels" % (ref["images"].shape[0], ref["pixels"].shape[0])
 
 
 def one_case(seed):

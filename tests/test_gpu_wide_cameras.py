@@ -147,8 +147,9 @@ class Data:
 
 @pytest.mark.parametrize("cam", ["kitti360_fisheye", "s3dis_equirectangular"])
 def test_map_images_wide_cameras(cam):
-    """MapImages (per-view path) with fisheye / equirectangular images against
-    the oracle's MapImages: nested CSR, pixels and features."""
+    """MapImages with fisheye / equirectangular images (fused all-view pass,
+    then the view-by-view path) against the oracle's MapImages: nested CSR,
+    pixels and features."""
     from mvfusion.images import SameSettingImageData
     from mvfusion.transforms import MapImages
     from test_gpu_parity import check_mapping
@@ -170,6 +171,11 @@ def test_map_images_wide_cameras(cam):
         extra = dict(opk=T(cams["opk"]))
     images = SameSettingImageData(pos=T(cams["pos"]), ref_size=ref_size, proj_upscale=2, **extra)
     t = MapImages(method="SplattingVisibility", cylinder=True, point_order="index", **vis)
+    assert t._fusable(images, t._settle(data, images))       # all views in one launch set
     _, out = t(data, images)
     assert out.num_views == ref["seen_images"].shape[0]
     check_mapping(out.mappings, ref)
+    # the view-by-view path gives the same mappings
+    images2 = SameSettingImageData(pos=T(cams["pos"]), ref_size=ref_size, proj_upscale=2, **extra)
+    m2, seen = t._process_per_view(data, images2, t._settle(data, images2), torch.device("cuda"))
+    check_mapping(m2, ref)
