@@ -67,8 +67,10 @@ class Data:
     pass
 
 
-def host_sample(scene, seed, n_views=None):
-    """Synthetic sample as the host tensors a data loader would hand over."""
+def host_sample(scene, seed, n_views=None, camera="pinhole"):
+    """Synthetic sample as the host tensors a data loader would hand over.
+    camera='equirect': the same cloud and camera positions seen through
+    S3DIS-style 2048 x 1024 equirectangular panoramas."""
     kw = {} if n_views is None else dict(n_views=n_views)
     # points in the order a voxel-grid sampler leaves them (the first pre-transform of the
     # reference's pipelines); MVF_BENCH_POINT_ORDER=random shuffles them instead
@@ -79,23 +81,36 @@ def host_sample(scene, seed, n_views=None):
     data = Data()
     data.pos = T(sc["xyz"])
     data.mapping_index = torch.arange(N)
+    if camera == "equirect":
+        V = sc["pos"].shape[0]
+        yaw = np.linspace(0, 2 * np.pi, V, endpoint=False)
+        sc["opk"] = np.stack([0.03 * np.cos(yaw), 0.05 * np.sin(yaw), yaw], 1).astype(np.float32)
+        sc["img_size"] = (2048, 1024)
+        images = SameSettingImageData(pos=T(sc["pos"]), opk=T(sc["opk"]), ref_size=sc["img_size"],
+                                      proj_upscale=1)
+        return sc, data, images
     images = SameSettingImageData(
         pos=T(sc["pos"]), extrinsic=T(sc["extrinsic"]), fx=T(sc["fx"]), fy=T(sc["fy"]),
         mx=T(sc["mx"]), my=T(sc["my"]), ref_size=sc["img_size"], proj_upscale=1)
     return sc, data, images
 
 
-def stage_sample(scene, seed, device, depth=False, n_views=None, exact=True):
+def stage_sample(scene, seed, device, depth=False, n_views=None, exact=True, camera="pinhole"):
     """Build one synthetic sample on the host and stage it in HBM."""
-    sc, data, images = host_sample(scene, seed, n_views)
+    sc, data, images = host_sample(scene, seed, n_views, camera)
     if depth:
         V = sc["pos"].shape[0]
-        K = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
-        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = sc["fx"], sc["fy"], sc["mx"], sc["my"]
         kw = {k: VIS[k] for k in ("voxel", "k_swell", "d_swell", "camera", "r_max", "r_min")}
-        images.depth_maps = visibility_module.render_depth_maps(
-            data.pos.to(device), images.pos, torch.from_numpy(K), images.extrinsic, sc["img_size"], **kw)
-        vis = {k: VIS[k] for k in ("r_max", "r_min", "camera")}
+        if camera == "equirect":
+            kw["camera"] = "s3dis_equirectangular"
+            images.depth_maps = visibility_module.render_depth_maps(
+                data.pos.to(device), images.pos, None, None, sc["img_size"], img_opk=images.opk, **kw)
+        else:
+            K = np.tile(np.eye(4, dtype=np.float32), (V, 1, 1))
+            K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = sc["fx"], sc["fy"], sc["mx"], sc["my"]
+            images.depth_maps = visibility_module.render_depth_maps(
+                data.pos.to(device), images.pos, torch.from_numpy(K), images.extrinsic, sc["img_size"], **kw)
+        vis = {k: kw[k] for k in ("r_max", "r_min", "camera")}
         t = MapImages(method="DepthBasedVisibility", cylinder=True, depth_threshold=0.05, **vis)
         model = visibility_module.DepthBasedVisibility(img_size=images.proj_size, depth_threshold=0.05, **vis)
     else:
@@ -356,8 +371,9 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     n_samples = wl.get("samples", 1)
     n_views = args.views if depth else None
     exact = bool(getattr(args, "exact", 1))
+    camera = getattr(args, "camera", "pinhole") if depth else "pinhole"
     staged = [stage_sample(wl["scene"], seed=2 + rank * n_samples + k, device=device, depth=depth,
-                           n_views=n_views, exact=exact) for k in range(n_samples)]
+                           n_views=n_views, exact=exact, camera=camera) for k in range(n_samples)]
     sc, plan = staged[0]
     N, V = plan.N, plan.V
     W, H = sc["img_size"]
@@ -562,6 +578,8 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     label = wl["label"]
     if depth:
         label += f" ({V} views per rank)"
+        if camera == "equirect":
+            label = label.replace("4 MP views", "2048x1024 equirectangular views")
     line = {
         "metric": "points*views mapped+fused/sec",
         "value": world * N_all * V * args.steps / elapsed,
@@ -647,6 +665,8 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="views of the c5 scene held by this rank")
     ap.add_argument("--exact", type=int, default=1,
                     help="0: plain splat visibility (every pixel a point wins is a mapping) for c1 / c2 / c4")
+    ap.add_argument("--camera", choices=["pinhole", "equirect"], default="pinhole",
+                    help="c5: equirect = S3DIS-style 2048x1024 equirectangular panoramas instead of 4 MP pinhole views")
     ap.add_argument("--batched", type=int, default=1,
                     help="c4: 1 maps the samples of a batch in one launch set, 0 one by one + torch collation")
     ap.add_argument("--lanes", type=int, default=3,

@@ -222,8 +222,9 @@ def read_s3dis_depth_map(path, img_size=None, empty=-1):
 
 def render_depth_maps(xyz, img_pos, img_intrinsic_pinhole, img_extrinsic, img_size, r_max=30,
                       r_min=0.5, voxel=0.1, k_swell=1.0, d_swell=1000,
-                      camera='kitti360_perspective', quantum=1.0 / 512):
-    """Depth maps [V, W, H] float32 of a cloud seen from V pinhole views, in the
+                      camera='kitti360_perspective', quantum=1.0 / 512, img_opk=None):
+    """Depth maps [V, W, H] float32 of a cloud seen from V views (pinhole, or
+    equirectangular with ``img_opk`` [V, 3] and no intrinsics / extrinsics), in the
     format ``read_s3dis_depth_map`` returns (visibility.py:1328-1358): the
     distance of the nearest splat per pixel (non-exact splat visibility of this
     library), rounded to ``quantum`` metres as the 16-bit PNGs are, -1 where no
@@ -234,15 +235,17 @@ def render_depth_maps(xyz, img_pos, img_intrinsic_pinhole, img_extrinsic, img_si
     V = img_pos.shape[0]
     out = torch.full((V, W, H), -1.0, dtype=torch.float32, device=device)
     for v in range(V):
+        cam_kw = dict(
+            img_intrinsic_pinhole=None if img_intrinsic_pinhole is None else img_intrinsic_pinhole[v],
+            img_extrinsic=None if img_extrinsic is None else img_extrinsic[v],
+            img_opk=None if img_opk is None else img_opk[v])
         idx, dist, x, y = camera_projection(
-            xyz_d, img_pos[v].float(), img_intrinsic_pinhole=img_intrinsic_pinhole[v],
-            img_extrinsic=img_extrinsic[v], img_size=(W, H), r_max=r_max, r_min=r_min,
-            camera=camera)
+            xyz_d, img_pos[v].float(), img_size=(W, H), r_max=r_max, r_min=r_min, camera=camera, **cam_kw)
         if idx.shape[0] == 0:
             continue
         vi, px, py = visibility_from_splatting(
-            x, y, dist, None, img_intrinsic_pinhole=img_intrinsic_pinhole[v], img_size=(W, H),
-            voxel=voxel, k_swell=k_swell, d_swell=d_swell, exact=False, camera=camera)
+            x, y, dist, None, img_size=(W, H), voxel=voxel, k_swell=k_swell, d_swell=d_swell,
+            exact=False, camera=camera, **cam_kw)
         d = torch.round(dist[vi].double() / quantum) * quantum
         out[v, px, py] = d.float()
     return out
