@@ -243,6 +243,12 @@ class Timer:
         return elapsed
 
 
+def split_mode():
+    from mvfusion import _lib
+    return "bf16 MFMA 32x32x16, operands split 3-way (6 products)" if _lib.load().mvf_get_mlp_precision() \
+        else "f32 MFMA 32x32x2"
+
+
 def run_qkv(args, rank, world, device, dist, cpu_leg=True):
     """C3: the attentive pool on synthetic CSR groups; one step = one forward."""
     from mvfusion import pooling
@@ -320,6 +326,15 @@ def run_qkv(args, rank, world, device, dist, cpu_leg=True):
                      "traffic": traffic,
                      "traffic_ratio": None if traffic is None else traffic / bytes_,
                      "flops_per_launch": flops, "kernel_ms": fwd_ms,
+                     # flops are those of the float32 layers (2 per multiply-add of the module);
+                     # the peak is the float32-input MFMA rate.  The value encoder (E_mod, 58 %
+                     # of them) runs on the bf16 matrix cores with three-way split operands: six
+                     # bf16 products per float32 product, float32 accuracy, 3/8 of the matrix-pipe
+                     # time of the float32 form; the narrow chains stay on the float32 form.
+                     "arithmetic": {"wide_chains": split_mode(), "narrow_chains": "f32 MFMA 32x32x2",
+                                    "bf16_mfma_flops_per_launch": 6 * 2 * Vw * 2 * Cm * Cm
+                                    if split_mode().startswith("bf16") else 0,
+                                    "bf16_peak": 2516.6},
                      "overlapped": {"ms_per_forward": elapsed / args.steps * 1e3,
                                     "achieved": flops / (elapsed / args.steps) / 1e12,
                                     "frac": flops / (elapsed / args.steps) / MFMA_F32_PEAK},

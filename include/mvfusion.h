@@ -505,6 +505,19 @@ int mvf_mlp_forward(
     int32_t mode, int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
     float *out, int32_t ldo, void *stream);
 
+/* Arithmetic of the layer chains.  mode 1 (default): chains of two layers that are both
+ * wider than 32 outputs, on at most 64 aligned and ungathered input columns (E_mod,
+ * pooling.py:757, 482-484, and the value encoders of the grouped pools, :272-300), run on
+ * the bf16 matrix cores with every float32 operand split exactly into three bf16 parts and
+ * the six significant part products accumulated in float32: the accuracy of the float32
+ * chain (the reference computes these layers with a float32 BLAS, whose summation order is
+ * not part of its contract) at 3/8 of its matrix-pipe time.  mode 0: every chain on the
+ * float32 matrix cores (exact fmaf chains).  The environment variable
+ * MVF_MLP_PRECISION=fp32 selects mode 0 at load time.  Process-wide; no counterpart in the
+ * reference. */
+int mvf_set_mlp_precision(int32_t mode);
+int mvf_get_mlp_precision(void);
+
 /* The same chain with a dot-product epilogue: the last layer's output y
  * [rows][cout <= 32] is not stored; instead
  *   dot_out[r] = sum_c y[r][c] * queries[row2seg[r]][c]     (/ divisor when divisor != 0)

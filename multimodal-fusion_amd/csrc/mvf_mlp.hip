@@ -271,6 +271,211 @@ __device__ __forceinline__ void atomic_max_float(float *p, float v)
     else atomicMin((unsigned *)p, __float_as_uint(v));
 }
 
+// Segment reduction of a wave's 32 finished rows (acc0 / acc1: the two blocks of 32 output
+// channels, lane = row jrow, channels acc_channel(r, kh)): the attention-weighted sum
+// (POOL 1 / 2, pooling.py:519-530) or the maximum (POOL 3, pooling.py:628).
+// The rows go through the wave's staging rows `stg` 16 at a time: a lane writes the 32 / 64
+// channels of its row (for the sum: times the row's attention weight), then lane c folds
+// channel c over the staged rows in row order.  The segment of a row is wave-uniform (read
+// from the row's lane), so segment changes are scalar branches.  A segment that lies inside
+// the tile is stored; one that continues in a neighbouring tile is combined atomically with
+// its preset row (zeros for the sum, -inf for the maximum).  pseg: the row's segment (-1 past
+// the end), pprev / pnext: the segments of the rows next to the tile, patt: the row's
+// attention weight (POOL 1); POOL 2 finds the tile's [32][groups] weights parked in `stg`.
+template <int POOL>
+__device__ __forceinline__ void mlp_pool_tail(
+    const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout, float *stg,
+    int pseg, int pprev, int pnext, float patt, int lane)
+{
+    const int jrow = lane & 31, kh = lane >> 5;
+    // rows times their attention weights, in place (POOL == 2: one weight per float4
+    // of channels, picked up from the parked [32][groups] block)
+    if (POOL == 2) {
+        // c0 / (cout / groups) as a multiply and shift, exact for c0 < 64
+        const unsigned inv = (65536u + (unsigned)(cout / A.pool_groups) - 1u) / (unsigned)(cout / A.pool_groups);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
+            if (q >= 4 && !wide) break;
+            const float w = c0 < cout ? stg[jrow * A.pool_groups + (int)(((unsigned)c0 * inv) >> 16)] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (q < 4) acc0[4 * (q & 3) + e] = __fmul_rn(acc0[4 * (q & 3) + e], w);
+                else acc1[4 * (q & 3) + e] = __fmul_rn(acc1[4 * (q & 3) + e], w);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if (POOL == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = __fmul_rn(acc0[r], patt);
+            if (wide) acc1[r] = __fmul_rn(acc1[r], patt);
+        }
+    }
+    int cur = __builtin_amdgcn_readlane(pseg, 0);
+    bool partial = cur == pprev;                 // the current segment began before this tile
+    // POOL == 3 folds with max instead of a sum (first row wins ties, as in the
+    // segment kernels); a partial maximum meets the others in a row preset to -inf
+    constexpr float FOLD0 = POOL == 3 ? -INFINITY : 0.f;
+    float accv = FOLD0;
+    auto flush = [&](int seg, float v, bool part) {
+        if (seg < 0 || lane >= cout) return;
+        float *o = A.pool_out + (size_t)seg * cout + lane;
+        if (!part) *o = v;
+        else if (POOL == 3) atomic_max_float(o, v);
+        else unsafeAtomicAdd(o, v);
+    };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if ((jrow >> 4) == half) {
+            float *p = stg + (jrow & 15) * POOL_PITCH + 4 * kh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4 *)(p + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+            if (wide) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4 *)(p + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float v[POOL_STAGE_ROWS];
+#pragma unroll
+        for (int i = 0; i < POOL_STAGE_ROWS; ++i) v[i] = stg[i * POOL_PITCH + lane];
+#pragma unroll
+        for (int i = 0; i < POOL_STAGE_ROWS; ++i) {
+            const int r = half * POOL_STAGE_ROWS + i;
+            const int s = __builtin_amdgcn_readlane(pseg, r);
+            if (s != cur) {
+                flush(cur, accv, partial);
+                partial = false;
+                cur = s;
+                accv = FOLD0;
+            }
+            if (POOL == 3) accv = v[i] > accv ? v[i] : accv;
+            else accv = __fadd_rn(accv, v[i]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // rows past the end carry segment -1: a tile that holds some has flushed its
+    // last segment at the change and ends with cur = -1
+    flush(cur, accv, partial || cur == pnext);
+}
+
+// The same reduction without LDS and without a serial walk over the rows: a segmented
+// inclusive scan over the lanes.  A lane's row jrow knows how far it is from the start of its
+// segment inside the tile (d, from a ballot of the segment starts); in steps of 1, 2, 4 and 8
+// lanes inside a DPP row of 16, and one step from lane 15 of the first row to the second row,
+// every lane whose segment reaches that far back adds the partial of the lane behind it,
+// for all of its 16 / 32 channel registers.  The last row of a segment then holds the
+// segment's result and writes it with 16-byte stores; a segment that continues in a
+// neighbouring tile is combined atomically as in mlp_pool_tail.  The sum
+// of a segment is a balanced tree over its rows instead of the in-order fold (deterministic,
+// same error bound, different last bits for segments of three and more rows).  Sums only
+// (POOL 1 / 2).  Needs cout % 4 == 0 and a 16-byte aligned output.  `stage2`: the wave's
+// staging rows; POOL 2 finds the tile's [32][groups] attention weights parked there.
+template <int POOL>
+__device__ __forceinline__ void mlp_pool_tail_scan(
+    const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout, float *stage2,
+    int pseg, int pprev, int pnext, float patt, int lane)
+{
+    static_assert(POOL == 1 || POOL == 2, "sums only");
+    const float *att_lds = stage2;
+    const int jrow = lane & 31, kh = lane >> 5;
+    if (POOL == 2) {
+        const unsigned inv = (65536u + (unsigned)(cout / A.pool_groups) - 1u) / (unsigned)(cout / A.pool_groups);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
+            if (q >= 4 && !wide) break;
+            const float w = c0 < cout ? att_lds[jrow * A.pool_groups + (int)(((unsigned)c0 * inv) >> 16)] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (q < 4) acc0[4 * (q & 3) + e] = __fmul_rn(acc0[4 * (q & 3) + e], w);
+                else acc1[4 * (q & 3) + e] = __fmul_rn(acc1[4 * (q & 3) + e], w);
+            }
+        }
+        // the parked weights are overwritten by the next tile: every lane is done with them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if (POOL == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc0[r] = __fmul_rn(acc0[r], patt);
+            if (wide) acc1[r] = __fmul_rn(acc1[r], patt);
+        }
+    }
+    // segment structure of the tile (the same in both lane halves)
+    const int behind = __shfl_up(pseg, 1, 64);
+    const bool is_start = jrow == 0 || pseg != behind;
+    const unsigned starts = (unsigned)__ballot(is_start);            // lanes 0 .. 31
+    const int first = 31 - __clz((int)(starts & (0xffffffffu >> (31 - jrow))));
+    const int d = jrow - first;                                      // rows of the segment behind this one
+    const int dd = d < (jrow & 15) ? d : (jrow & 15);                // ... inside the DPP row of 16 lanes
+    const bool is_end = jrow == 31 || ((starts >> (jrow + 1)) & 1u);
+    // One step for all registers: v += partial of the lane `shift` behind, times the lane's 0 / 1
+    // mask, as one v_fmac_f32 with a DPP source (times 1 and plus 0 are exact).  No branch: a
+    // DPP read from a lane that is switched off returns nothing, so every lane stays active.
+    // A DPP read needs two wait states after a vector write of the register: inside a step the
+    // instructions touch different registers, and the s_nop in front of a step covers the
+    // writes of the step (or the multiplication) before it.
+#define MVF_SCAN_STEP(COND_, DPP_)                                                                \
+    {                                                                                             \
+        const float m_ = (COND_) ? 1.f : 0.f;                                                     \
+        asm volatile("s_nop 1" ::: "memory");                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+            asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPP_ : "+v"(acc0[r]) : "v"(m_));            \
+            if (wide) asm volatile("v_fmac_f32_dpp %0, %0, %1 " DPP_ : "+v"(acc1[r]) : "v"(m_));  \
+        }                                                                                         \
+    }
+    MVF_SCAN_STEP(dd >= 1, "row_shr:1 row_mask:0xf bank_mask:0xf")
+    MVF_SCAN_STEP(dd >= 2, "row_shr:2 row_mask:0xf bank_mask:0xf")
+    MVF_SCAN_STEP(dd >= 4, "row_shr:4 row_mask:0xf bank_mask:0xf")
+    MVF_SCAN_STEP(dd >= 8, "row_shr:8 row_mask:0xf bank_mask:0xf")
+    MVF_SCAN_STEP((jrow & 16) && d > (jrow & 15), "row_bcast:15 row_mask:0xa bank_mask:0xf")
+#undef MVF_SCAN_STEP
+    // Segments that continue in a neighbouring tile (at most the first and the last one, known
+    // wave-wide) go through two staging rows so that one atomic instruction adds 64 channels.
+    const int seg0 = __builtin_amdgcn_readlane(pseg, 0), seg31 = __builtin_amdgcn_readlane(pseg, 31);
+    const bool part1 = seg31 >= 0 && seg31 == pnext;
+    const bool part0 = seg0 >= 0 && seg0 == pprev && !(part1 && seg0 == seg31);
+    const bool mine_partial = (part0 && pseg == seg0) || (part1 && pseg == seg31);
+    if (is_end && pseg >= 0) {
+        float *o = mine_partial ? stage2 + (pseg == seg31 && part1 ? POOL_PITCH : 0) + 4 * kh
+                                : A.pool_out + (size_t)pseg * cout + 4 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (8 * g + 4 * kh < cout)
+                *(float4 *)(o + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+            if (wide && 32 + 8 * g + 4 * kh < cout)
+                *(float4 *)(o + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+        }
+    }
+    if (part0 || part1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (part0 && lane < cout) unsafeAtomicAdd(A.pool_out + (size_t)seg0 * cout + lane, stage2[lane]);
+        if (part1 && lane < cout) unsafeAtomicAdd(A.pool_out + (size_t)seg31 * cout + lane, stage2[POOL_PITCH + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // NL / WMASK >= 0 fix the number of layers and which of them are wider than 32
 // outputs (bit l of WMASK) at compile time, for the aligned single-source or
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
@@ -595,101 +800,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             }
         }
     pool_tail:
-        if (POOL) {
-            // Segment reduction of the finished rows: the attention-weighted sum
-            // (POOL 1 / 2, pooling.py:519-530) or the maximum (POOL 3, pooling.py:628).
-            // The wave's 32 rows go through LDS 16 at a time: a lane writes the 32 / 64
-            // channels of its row (for the sum: times the row's attention weight), then
-            // lane c folds channel c over the staged rows in row order.  The segment of a
-            // row is wave-uniform (read from the row's lane), so segment changes are scalar
-            // branches.  A segment that lies inside the tile is stored; one that continues
-            // in a neighbouring tile is combined atomically with its preset row (zeros for
-            // the sum, -inf for the maximum).
-            const bool wide = cop_of(nlayers - 1) > 32;
-            const int cout = A.L[nlayers - 1].cout;
-            float *stg = smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH);
-            // rows times their attention weights, in place (POOL == 2: one weight per float4
-            // of channels, picked up from the parked [32][groups] block)
-            if (POOL == 2) {
-                // c0 / (cout / groups) as a multiply and shift, exact for c0 < 64
-                const unsigned inv = (65536u + (unsigned)(cout / A.pool_groups) - 1u) / (unsigned)(cout / A.pool_groups);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int c0 = (q >> 2) * 32 + 8 * (q & 3) + 4 * kh;
-                    if (q >= 4 && !wide) break;
-                    const float w = c0 < cout ? stg[jrow * A.pool_groups + (int)(((unsigned)c0 * inv) >> 16)] : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (q < 4) acc0[4 * (q & 3) + e] = __fmul_rn(acc0[4 * (q & 3) + e], w);
-                        else acc1[4 * (q & 3) + e] = __fmul_rn(acc1[4 * (q & 3) + e], w);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else if (POOL == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc0[r] = __fmul_rn(acc0[r], patt);
-                    if (wide) acc1[r] = __fmul_rn(acc1[r], patt);
-                }
-            }
-            int cur = __builtin_amdgcn_readlane(pseg, 0);
-            bool partial = cur == pprev;                 // the current segment began before this tile
-            // POOL == 3 folds with max instead of a sum (first row wins ties, as in the
-            // segment kernels); a partial maximum meets the others in a row preset to -inf
-            constexpr float FOLD0 = POOL == 3 ? -INFINITY : 0.f;
-            float accv = FOLD0;
-            auto flush = [&](int seg, float v, bool part) {
-                if (seg < 0 || lane >= cout) return;
-                float *o = A.pool_out + (size_t)seg * cout + lane;
-                if (!part) *o = v;
-                else if (POOL == 3) atomic_max_float(o, v);
-                else unsafeAtomicAdd(o, v);
-            };
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if ((jrow >> 4) == half) {
-                    float *p = stg + (jrow & 15) * POOL_PITCH + 4 * kh;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *(float4 *)(p + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
-                    if (wide) {
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            *(float4 *)(p + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float v[POOL_STAGE_ROWS];
-#pragma unroll
-                for (int i = 0; i < POOL_STAGE_ROWS; ++i) v[i] = stg[i * POOL_PITCH + lane];
-#pragma unroll
-                for (int i = 0; i < POOL_STAGE_ROWS; ++i) {
-                    const int r = half * POOL_STAGE_ROWS + i;
-                    const int s = __builtin_amdgcn_readlane(pseg, r);
-                    if (s != cur) {
-                        flush(cur, accv, partial);
-                        partial = false;
-                        cur = s;
-                        accv = FOLD0;
-                    }
-                    if (POOL == 3) accv = v[i] > accv ? v[i] : accv;
-                    else accv = __fadd_rn(accv, v[i]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            // rows past the end carry segment -1: a tile that holds some has flushed its
-            // last segment at the change and ends with cur = -1
-            flush(cur, accv, partial || cur == pnext);
-        }
+        if (POOL)
+            mlp_pool_tail<POOL>(A, acc0, acc1, cop_of(nlayers - 1) > 32, A.L[nlayers - 1].cout,
+                                smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH),
+                                pseg, pprev, pnext, patt, lane);
     tile_done:;
     }
 }
@@ -708,6 +822,356 @@ __global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(3))
 void mlp_chain_pool_kernel(MlpArgs A)
 {
     mlp_chain_body<NL, WMASK, POOL, XQ>(A);
+}
+
+// ------------------------------------------------------------------------- //
+// wide two-layer chains on the bf16 matrix cores, float32 accuracy           //
+// ------------------------------------------------------------------------- //
+// v_mfma_f32_32x32x16_bf16 runs at 16 times the rate of the float32 form.  A float32 value
+// splits exactly into three bf16 parts, x = x1 + x2 + x3 (each the round-to-nearest bf16 of
+// what the parts before it leave; the remainders are exact float32 subtractions), and the
+// product of two split values is the sum of nine part products that are exact in float32.
+// The six of weight 2^-16 and above -- (1,1) (1,2) (2,1) (2,2) (1,3) (3,1), added smallest
+// first -- leave out less than 2^-23 of the product, the rounding of a float32 multiply: six
+// bf16 MFMAs do the work of eight float32 MFMAs in 3/8 of the matrix-pipe time, with the
+// accuracy of the float32 chain (measured against float64 on random layers: 3.4e-6 against
+// 4.6e-6 for a float32 dot product at magnitude 13).  Nothing overflows or loses range: bf16
+// has float32's exponent.
+//
+// The price is vector work: 11 instructions per pair of values to split (v_cvt_pk_bf16_f32,
+// two shifts / masks, two subtractions, twice over, and a last conversion), 60 per k-step of 8
+// values with the activation.  A wave issues in order and an MFMA holds the vector issue port
+// for 8 of its 32 cycles, so the split of the NEXT k-step is written between the MFMAs of the
+// current one, five instructions per gap, in stage-major order (neighbouring instructions do
+// not depend on each other) and fenced with scheduling barriers so that the order survives
+// the compiler.  One wave per SIMD (one workgroup per CU): two such streams on one SIMD only
+// take matrix-pipe slots from each other.
+//
+// Layout as in the float32 chain: Y^T = W X^T, a lane owns row jrow = lane & 31, the 16
+// accumulators of a block are the next layer's B operand without any lane movement.  The k
+// order of a step follows what a lane holds: first layer, k-step q, lane half kh, element j
+// = input column kh * S + 8 q + j (S = 8 * k-steps: the lane's contiguous half of its row);
+// later layers, k-step q = registers 8 (q & 1) .. + 7 of block q >> 1, i.e. input channel
+// 32 (q >> 1) + acc_channel(8 (q & 1) + j, kh).  The weights sit in LDS already multiplied
+// by the channel scale, split, and in that order: [layer][k-step][out block][part][lane]
+// x 16 bytes, one conflict-free ds_read_b128 per operand, requested one k-step ahead.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#define MVF_SB() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
+{
+    floatx2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// v_max_f32 as written: fmaxf() first passes an operand of unknown origin (an MFMA result)
+// through another v_max_f32 to quiet a signalling NaN, one more instruction per value.
+__device__ __forceinline__ float max_raw(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// The split of 8 values (after the activation of the layer that produced them) as a list of
+// single vector instructions in stage-major order; 44 operations, 60 with the activation.
+struct Bf3Split {
+    float x[8], t[8];
+    unsigned d[4], h[4], g[4];
+    uintx4 p1, p2, p3;
+    __device__ __forceinline__ void op(int i, const float *v, bool act, float slope)
+    {
+        if (act) {
+            // leaky(v) = max(v, slope v) for slope <= 1; no activation is slope 1
+            if (i < 8) { t[i] = __fmul_rn(v[i], slope); return; }
+            if (i < 16) { x[i - 8] = max_raw(v[i - 8], t[i - 8]); return; }
+            i -= 16;
+        }
+        const int st = i >> 2, e = i & 3;
+        switch (st) {
+        case 0:
+            if (!act) { x[2 * e] = v[2 * e]; x[2 * e + 1] = v[2 * e + 1]; }
+            d[e] = cvt_pk_bf16(x[2 * e], x[2 * e + 1]); p1[e] = d[e];
+            break;
+        case 1: case 6: h[e] = d[e] << 16; break;
+        case 2: case 7: g[e] = d[e] & 0xffff0000u; break;
+        case 3: case 8: x[2 * e] = __fsub_rn(x[2 * e], __uint_as_float(h[e])); break;
+        case 4: case 9: x[2 * e + 1] = __fsub_rn(x[2 * e + 1], __uint_as_float(g[e])); break;
+        case 5: d[e] = cvt_pk_bf16(x[2 * e], x[2 * e + 1]); p2[e] = d[e]; break;
+        default: p3[e] = cvt_pk_bf16(x[2 * e], x[2 * e + 1]); break;
+        }
+    }
+    // piece i of n equal pieces of the list
+    __device__ __forceinline__ void piece(int i, int n, const float *v, bool act, float slope)
+    {
+        const int total = act ? 60 : 44, per = (total + n - 1) / n;
+#pragma unroll
+        for (int k = i * per; k < (i + 1) * per; ++k)
+            if (k < total) op(k, v, act, slope);
+    }
+    __device__ __forceinline__ void all(const float *v, bool act, float slope) { piece(0, 1, v, act, slope); }
+};
+
+__device__ __forceinline__ floatx16 mfma_bf16(const uintx4 &a, const uintx4 &b, floatx16 acc)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// One k-step into both output blocks: 12 MFMAs, after each of them piece i of `fill`.  The
+// weights of this step are in `a` (block 0 parts 1..3, block 1 parts 1..3); those of the next
+// step, at `nxt`, are requested first and replace them at the end.
+template <class F>
+__device__ __forceinline__ void bf3_kstep(
+    uintx4 (&a)[6], const uintx4 *nxt, const uintx4 (&b)[3], floatx16 &n0, floatx16 &n1, F fill)
+{
+    uintx4 t[6];
+    MVF_SB();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i] = nxt[i * 64];
+    MVF_SB();
+    n0 = mfma_bf16(a[0], b[2], n0); MVF_SB(); fill(0); MVF_SB();
+    n0 = mfma_bf16(a[2], b[0], n0); MVF_SB(); fill(1); MVF_SB();
+    n0 = mfma_bf16(a[1], b[1], n0); MVF_SB(); fill(2); MVF_SB();
+    n0 = mfma_bf16(a[0], b[1], n0); MVF_SB(); fill(3); MVF_SB();
+    n0 = mfma_bf16(a[1], b[0], n0); MVF_SB(); fill(4); MVF_SB();
+    n0 = mfma_bf16(a[0], b[0], n0); MVF_SB(); fill(5); MVF_SB();
+    n1 = mfma_bf16(a[3], b[2], n1); MVF_SB(); fill(6); MVF_SB();
+    n1 = mfma_bf16(a[5], b[0], n1); MVF_SB(); fill(7); MVF_SB();
+    n1 = mfma_bf16(a[4], b[1], n1); MVF_SB(); fill(8); MVF_SB();
+    n1 = mfma_bf16(a[3], b[1], n1); MVF_SB(); fill(9); MVF_SB();
+    n1 = mfma_bf16(a[4], b[0], n1); MVF_SB(); fill(10); MVF_SB();
+    n1 = mfma_bf16(a[3], b[0], n1); MVF_SB(); fill(11); MVF_SB();
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a[i] = t[i];
+}
+
+// 16-byte vectors of one layer's LDS image with nq k-steps
+__host__ __device__ __forceinline__ int bf3_layer_vecs(int nq) { return nq * 2 * 3 * 64; }
+
+// Two layers, both wider than 32 outputs; first layer of at most 64 input columns (a multiple
+// of 4, one source or two concatenated ones, 16-byte aligned rows, no row gathers).  NQ0:
+// k-steps of the first layer (16 input columns each).  POOL as in mlp_chain_body.
+template <int NQ0, int POOL>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void mlp_wide2_bf3_kernel(MlpArgs A)
+{
+    extern __shared__ float smem[];
+    float *sc = smem;                                   // [2][64] channel scales
+    float *sh = sc + 2 * MLP_MAX_C;                     // [2][64] channel shifts
+    uintx4 *wl = (uintx4 *)(smem + 4 * MLP_MAX_C);      // the split weights of both layers
+    float *stage = (float *)(wl + bf3_layer_vecs(NQ0) + bf3_layer_vecs(4));
+    constexpr int S = 8 * NQ0;                          // columns of a lane half in the first layer
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jrow = lane & 31, kh = lane >> 5;
+    const int cin0 = A.L[0].cin;
+    for (int idx = tid; idx < 2 * MLP_MAX_C; idx += MLP_THREADS) {
+        const int l = idx / MLP_MAX_C, j = idx - l * MLP_MAX_C;
+        const mvf_mlp_layer &L = A.L[l];
+        float s = 0.f, t = 0.f;
+        if (j < L.cout) {
+            s = 1.f;
+            if (L.bn_weight) {
+                s = __fdiv_rn(L.bn_weight[j], sqrtf(__fadd_rn(L.bn_var[j], L.bn_eps)));
+                t = __fsub_rn(L.bn_bias[j], __fmul_rn(L.bn_mean[j], s));
+            }
+            if (L.bias) t = __fadd_rn(__fmul_rn(L.bias[j], s), t);
+        }
+        sc[idx] = s;
+        sh[idx] = t;
+    }
+    __syncthreads();
+    // split weights (times the channel scale), zero beyond the layer's rows and columns
+    for (int idx = tid; idx < (NQ0 + 4) * 2 * 64; idx += MLP_THREADS) {
+        const int ln = idx & 63, nbo = (idx >> 6) & 1, qq = idx >> 7;
+        const int l = qq >= NQ0, q = l ? qq - NQ0 : qq;
+        const mvf_mlp_layer &L = A.L[l];
+        const int m = nbo * 32 + (ln & 31), h = ln >> 5;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 8 * (q & 1) + j;
+            const int k = l ? 32 * (q >> 1) + acc_channel(r, h) : h * S + 8 * q + j;
+            v[j] = (k < L.cin && m < L.cout) ? __fmul_rn(L.weight[(size_t)m * L.cin + k], sc[l * MLP_MAX_C + m]) : 0.f;
+        }
+        Bf3Split sp;
+        sp.all(v, false, 1.f);
+        uintx4 *dst = wl + (l ? bf3_layer_vecs(NQ0) : 0) + ((q * 2 + nbo) * 3) * 64 + ln;
+        dst[0] = sp.p1; dst[64] = sp.p2; dst[128] = sp.p3;
+    }
+    __syncthreads();
+
+    const i64 stride = (i64)gridDim.x * MLP_ROWS;
+    i64 base = (i64)blockIdx.x * MLP_ROWS;
+    if (base >= A.rows) return;
+    // Piece q (8 columns) of the lane's half of its row in tile `b`; columns past the row's
+    // end re-read column 0 (their weights are zero), rows past the end re-read row 0.
+    float xr[4 * 2 * NQ0], xn[4 * 2 * NQ0];              // this tile's rows, the next tile's
+    auto load_piece = [&](float *dst, i64 b, int q) {
+        i64 r = b + wave * 32 + jrow;
+        if (r >= A.rows) r = 0;
+        const float *pa = A.a.p + r * A.a.ld;
+        const float *pb = A.b.p ? A.b.p + r * A.b.ld : pa;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int c = kh * S + 8 * q + 4 * u;
+            if (c >= cin0) c = 0;
+            const float4 t = ld4(c < A.a.cols ? pa + c : pb + (c - A.a.cols));
+            dst[8 * q + 4 * u] = t.x; dst[8 * q + 4 * u + 1] = t.y; dst[8 * q + 4 * u + 2] = t.z; dst[8 * q + 4 * u + 3] = t.w;
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < NQ0; ++q) load_piece(xr, base, q);
+    Bf3Split sp;
+    uintx4 cur[3];                                      // the split k-step about to be multiplied
+    sp.all(xr, false, 1.f);
+    cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+    const mvf_mlp_layer &L0 = A.L[0], &L1 = A.L[1];
+    const float slope0 = L0.act ? L0.slope : 1.f;
+    uintx4 aw[6];                                       // weights of the k-step about to run
+#pragma unroll
+    for (int i = 0; i < 6; ++i) aw[i] = wl[i * 64 + lane];
+    // no load is in flight when the tile loop is entered, as at its back edge (see the wait in
+    // front of the last k-step): a wait inside the loop for the first tile's rows would be a
+    // wait for every load of every tile
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0)
+#ifdef MVF_BF3_STAMP
+    long long st_[16] = {0}; int nt_ = 0;
+    const long long w0_ = wall_clock64(), c0_ = clock64();
+#define STAMP(i_) { const long long n_ = clock64(); st_[i_] += n_ - last_; last_ = n_; }
+#else
+#define STAMP(i_) {}
+#endif
+    for (; base < A.rows; base += stride) {
+#ifdef MVF_BF3_STAMP
+        long long last_ = clock64(); ++nt_;
+#endif
+        const i64 row = base + wave * 32 + jrow;
+        const bool live = row < A.rows;
+        // the weights are re-read for every tile (in registers they would take 192 of them)
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        const uintx4 *w0 = wl + lofs;                   // the second layer's image follows the first
+        // pool epilogue: the row's segment and attention weight now (see mlp_chain_body)
+        int pseg = -1, pprev = -1, pnext = -1;
+        float patt = 0.f;
+        float pa[POOL_MAX_GROUPS / 2];
+        if (POOL) {
+            const i64 t0 = base + wave * 32;
+            if (live) pseg = A.dot_seg[row];
+            if (POOL == 1 && live) patt = A.pool_att[row];
+            if (POOL == 2) {
+                const i64 first = t0 * A.pool_groups, stop = A.rows * A.pool_groups;
+#pragma unroll
+                for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k) {
+                    const int idx = lane + 64 * k;
+                    pa[k] = (idx < 32 * A.pool_groups && first + idx < stop) ? A.pool_att[first + idx] : 0.f;
+                }
+            }
+            if (t0 > 0 && t0 < A.rows) pprev = A.dot_seg[t0 - 1];
+            if (t0 + POOL_TILE < A.rows) pnext = A.dot_seg[t0 + POOL_TILE];
+        }
+        // the next tile's rows, a whole tile ahead of their first use (the split of piece 0 at
+        // the end of this tile): under load a row takes longer to arrive than one layer runs
+#pragma unroll
+        for (int q = 0; q < NQ0; ++q) load_piece(xn, base + stride, q);
+        floatx16 acc0, acc1, n0, n1;
+        mlp_init_acc(acc0, 0, sh, kh);
+        mlp_init_acc(acc1, 1, sh, kh);
+        mlp_init_acc(n0, 0, sh + MLP_MAX_C, kh);
+        mlp_init_acc(n1, 1, sh + MLP_MAX_C, kh);
+        STAMP(3)
+        // ---- first layer: k-step q runs beside the split of piece q + 1, whose registers
+        // are then refilled for the next tile ----
+#pragma unroll
+        for (int q = 0; q < NQ0; ++q) {
+            if (q > 0) { STAMP(3 + q) }
+            if (q + 1 < NQ0) {
+                bf3_kstep(aw, w0 + ((q + 1) * 6) * 64, cur, acc0, acc1,
+                          [&](int i) { sp.piece(i, 12, xr + 8 * (q + 1), false, 1.f); });
+                cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+            } else {
+                // last k-step: the first 8 channels of the result are not finished yet
+                bf3_kstep(aw, w0 + ((q + 1) * 6) * 64, cur, acc0, acc1, [&](int) {});
+            }
+        }
+        if (POOL == 2) {
+            float *stg_att = stage + wave * (POOL_STAGE_ROWS * POOL_PITCH);
+#pragma unroll
+            for (int k = 0; k < POOL_MAX_GROUPS / 2; ++k)
+                if (lane + 64 * k < 32 * A.pool_groups) stg_att[lane + 64 * k] = pa[k];
+        }
+        STAMP(0)
+        // ---- second layer ----
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = acc0[j];
+        sp.all(v8, true, slope0);
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+        STAMP(8)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q > 0) { STAMP(8 + q) }
+            if (q < 3) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v8[j] = ((q + 1) >> 1) ? acc1[8 * ((q + 1) & 1) + j] : acc0[8 * ((q + 1) & 1) + j];
+                bf3_kstep(aw, w0 + ((NQ0 + q + 1) * 6) * 64, cur, n0, n1,
+                          [&](int i) { sp.piece(i, 12, v8, true, slope0); });
+            } else {
+                // Every load of this tile (the next tile's rows and the pool's per-row values,
+                // requested at its start) has landed by now: waiting for all of them here costs
+                // little and leaves only the epilogue's stores in flight at the next tile's
+                // start.  Without it the first wait of the next tile, behind the epilogue's
+                // branches, is a wait for everything including that tile's own loads.
+                __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+                STAMP(12)
+                // the next tile's piece 0; the weights of the first layer's first step
+                bf3_kstep(aw, w0, cur, n0, n1, [&](int i) { sp.piece(i, 12, xn, false, 1.f); });
+            }
+            cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+        }
+        // the split parts are due here: without this the compiler moves the last fill, whose
+        // results only the next tile uses, behind the epilogue's branches
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]));
+        STAMP(1)
+        // ---- activation of the last layer, then rows out or into the segment reduction ----
+        const float slope1 = L1.act ? L1.slope : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            n0[r] = max_raw(n0[r], __fmul_rn(n0[r], slope1));
+            n1[r] = max_raw(n1[r], __fmul_rn(n1[r], slope1));
+        }
+        if ((POOL == 0 || POOL == 3) && live) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mlp_store4(n0, 0, g, A, true, L1.cout, row, kh);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mlp_store4(n1, 1, g, A, true, L1.cout, row, kh);
+        }
+        if (POOL == 1 || POOL == 2)
+            mlp_pool_tail_scan<POOL == 2 ? 2 : 1>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
+                                                  pseg, pprev, pnext, patt, lane);
+        else if (POOL == 3)
+            mlp_pool_tail<3>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
+                             pseg, pprev, pnext, patt, lane);
+#pragma unroll
+        for (int t = 8; t < 8 * NQ0; ++t) xr[t] = xn[t];
+        STAMP(2)
+    }
+#ifdef MVF_BF3_STAMP
+    if (blockIdx.x == 9 && tid == 0)
+        printf("tiles %d: start %lld | L1 k0 %lld k1 %lld k2 %lld k3+park %lld | split %lld | L2 k0 %lld k1 %lld k2 %lld wait %lld k3 %lld | tail %lld cycles per tile, %.0f MHz\n", nt_,
+               st_[3] / nt_, st_[4] / nt_, st_[5] / nt_, st_[6] / nt_, st_[0] / nt_, st_[8] / nt_, st_[9] / nt_, st_[10] / nt_, st_[11] / nt_, st_[12] / nt_, st_[1] / nt_, st_[2] / nt_,
+               (double)(clock64() - c0_) / (double)(wall_clock64() - w0_) * 100.0);
+#endif
+}
+
+static size_t bf3_lds_bytes(int nq0, bool pool)
+{
+    return sizeof(float) * 4 * MLP_MAX_C + 16 * (size_t)(bf3_layer_vecs(nq0) + bf3_layer_vecs(4)) +
+           (pool ? sizeof(float) * MLP_WAVES * POOL_STAGE_ROWS * POOL_PITCH : 0);
 }
 
 // ------------------------------------------------------------------------- //
@@ -986,6 +1450,22 @@ static size_t mlp_lds_bytes(const mvf_mlp_layer *L, int n)
 
 using namespace mvf;
 
+// 1: wide layer chains run on the bf16 matrix cores with three-way split operands
+// (float32 accuracy); 0: every chain on the float32 matrix cores (exact fmaf chains).
+static int g_mlp_precision = [] {
+    const char *e = getenv("MVF_MLP_PRECISION");
+    return (e && (e[0] == 'f' || e[0] == '0')) ? 0 : 1;      // "fp32" / "0" select the float32 cores
+}();
+
+extern "C" int mvf_set_mlp_precision(int32_t mode)
+{
+    MVF_REQUIRE(mode == 0 || mode == 1, "set_mlp_precision: mode %d (0 = float32 matrix cores, 1 = split bf16)", mode);
+    g_mlp_precision = mode;
+    return MVF_OK;
+}
+
+extern "C" int mvf_get_mlp_precision(void) { return g_mlp_precision; }
+
 #ifdef MVF_MLP_DEBUG
 extern "C" int mvf_debug_mlp_switch(int mask)
 {
@@ -1121,6 +1601,41 @@ static int mlp_forward_impl(
         else if ((WM_) == 0 && xq == 4) MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 4);                  \
         else MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 8);                                             \
     } while (0)
+    // two wide layers on at most 64 aligned, ungathered input columns: bf16 matrix cores
+    if (g_mlp_precision != 0 && fixed && nlayers == 2 && wmask == 3 && cin0 <= MLP_KC && !gather_a && !gather_b && !dot_out &&
+        (!pool_out || (layers[1].cout % 4 == 0 && (uintptr_t)pool_out % 16 == 0))) {
+        const int nq0 = (cin0 + 15) / 16;
+        const size_t lds3 = bf3_lds_bytes(nq0, pool_out != nullptr);
+        // two workgroups per CU: the epilogue of one wave runs beside the MFMAs of the other
+        int wg_per_cu = 2;
+#ifdef MVF_MLP_DEBUG
+        if (const char *e = getenv("MVF_BF3_WGS")) wg_per_cu = atoi(e);
+#endif
+        const i64 cap3 = (i64)cus * (wg_per_cu < 1 ? 1 : wg_per_cu);
+        dim3 grid3((unsigned)(want < cap3 ? want : cap3));
+        const int pool = !pool_out ? 0 : pool_max ? 3 : pool_groups == 1 ? 1 : 2;
+#define MVF_BF3_LAUNCH(NQ_, P_)                                                                  \
+    do {                                                                                         \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_wide2_bf3_kernel<NQ_, P_>,                 \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));     \
+        hipLaunchKernelGGL((mlp_wide2_bf3_kernel<NQ_, P_>), grid3, dim3(MLP_THREADS), lds3, st, A); \
+    } while (0)
+#define MVF_BF3_LAUNCH_P(NQ_)                                                                    \
+    do {                                                                                         \
+        if (pool == 0) MVF_BF3_LAUNCH(NQ_, 0);                                                   \
+        else if (pool == 1) MVF_BF3_LAUNCH(NQ_, 1);                                              \
+        else if (pool == 2) MVF_BF3_LAUNCH(NQ_, 2);                                              \
+        else MVF_BF3_LAUNCH(NQ_, 3);                                                             \
+    } while (0)
+        if (nq0 == 1) MVF_BF3_LAUNCH_P(1);
+        else if (nq0 == 2) MVF_BF3_LAUNCH_P(2);
+        else if (nq0 == 3) MVF_BF3_LAUNCH_P(3);
+        else MVF_BF3_LAUNCH_P(4);
+#undef MVF_BF3_LAUNCH
+#undef MVF_BF3_LAUNCH_P
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     if (pool_out) {
         MVF_REQUIRE(fixed && nlayers == 2 && (wmask == 0 || wmask == 3),
                     "mlp_forward_pool: two layers of equal output width on 16-byte aligned, unsummed inputs only");

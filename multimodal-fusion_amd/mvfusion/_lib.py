@@ -121,6 +121,8 @@ _SIGNATURES = {
                                          _P, _I64, _P, _P, _P]),
     "mvf_attention_pool": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32,
                                      _I32, _I32, _I32, _F, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "mvf_set_mlp_precision": (C.c_int, [_I32]),
+    "mvf_get_mlp_precision": (C.c_int, []),
     "mvf_csr_row_segments": (C.c_int, [_P, _I64, _P, _P]),
     "mvf_segment_pick": (C.c_int, [_P, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "mvf_gather_features_backward": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P, _P]),

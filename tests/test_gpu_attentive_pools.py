@@ -257,7 +257,8 @@ def test_mlp_chain_dot_epilogue():
 def test_mlp_chain_pool_epilogue(C, gating, G):
     """The value encoder with the attention-weighted segment sum as epilogue
     against encoder launch + attention_pool on the same compatibilities:
-    identical bits (without a gate) for every segment inside one 32-row tile, 1e-6 of the output
+    identical bits (without a gate) for every segment inside one 32-row tile (wide chains: of at
+    most two rows, their sums are trees), 1e-6 of the output
     scale for the segments that cross a tile boundary; empty segments, segments of
     more than 64 rows (three tiles) and a ragged last tile included.  A gate is
     folded into the attention weights, so with one every segment is compared at
@@ -302,7 +303,12 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
     assert inside.sum() > 0.8 * N and (~inside).sum() > 100
     m = torch.from_numpy(inside).to(DEV)
     if not gating:
-        assert torch.equal(fused[m], plain[m])
+        # chains of layers wider than 32 run the scan epilogue (a balanced tree over a segment's rows
+        # instead of the in-order fold): there only segments of at most two rows keep every bit
+        same_order = inside if C <= 32 else inside & (counts <= 2)
+        assert same_order.sum() > 1000
+        ms = torch.from_numpy(same_order).to(DEV)
+        assert torch.equal(fused[ms], plain[ms])
     _close(fused, plain.cpu().numpy(), rtol=1e-6)
     assert float(fused[T(counts == 0)].abs().max()) == 0.0
     # run to run: only sums of three or more tile partials may change bits
@@ -352,3 +358,47 @@ def test_mlp_chain_segment_max_epilogue(cin, C):
     assert torch.equal(rows, want_rows)
     assert torch.equal(smax, want_max)
     assert float(smax[T(counts == 0)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cin,mid,cout,scale", [(64, 64, 64, 1.0), (16, 48, 64, 1.0), (40, 64, 36, 1.0),
+                                                (8, 33, 64, 1e-6), (64, 64, 64, 1e6), (24, 64, 48, 1.0)])
+def test_wide_chain_on_split_bf16_matches_float32_chain(cin, mid, cout, scale):
+    """Chains of two wide layers run on the bf16 matrix cores with three-way split operands
+    (mvf_set_mlp_precision 1, the default): against the same chain on the float32 matrix cores
+    (mode 0) and against a float64 evaluation, over input widths that leave padded k-steps, very
+    small and very large magnitudes (bf16 keeps float32's exponent range), negative slopes'
+    branch, signed zeros and a ragged last tile.  Both float32 paths must be as close to float64
+    as a float32 dot product is: 2e-6 of the row's magnitude."""
+    from mvfusion import _lib, dense
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 1000 + cout)
+    rows = 5003
+    x = ((rng.random((rows, cin)) * 2 - 1) * scale).astype(np.float32)
+    x[rng.random((rows, cin)) < 0.05] = 0.0
+    x[7] = -0.0
+    torch.manual_seed(cin + cout)
+    mlp = _random_module(pooling.MLP([cin, mid, cout], bias=False), 5).to(DEV).eval()
+    specs = dense.mlp_layers(mlp)
+    assert lib.mvf_get_mlp_precision() == 1
+    got = dense.run_layers(specs, T(x))
+    try:
+        assert lib.mvf_set_mlp_precision(0) == 0
+        plain = dense.run_layers(specs, T(x))
+    finally:
+        lib.mvf_set_mlp_precision(1)
+    # float64 evaluation of Linear (no bias) -> BatchNorm1d (eval) -> LeakyReLU(0.2), twice
+    sd = {k: v.double().cpu().numpy() for k, v in mlp.state_dict().items()}
+    want = x.astype(np.float64)
+    for i in range(2):
+        want = want @ sd[f"{i}.0.weight"].T
+        bn = f"{i}.1.batch_norm."
+        want = (want - sd[bn + "running_mean"]) / np.sqrt(sd[bn + "running_var"] + mlp[i][1].batch_norm.eps) \
+            * sd[bn + "weight"] + sd[bn + "bias"]
+        want = np.where(want > 0, want, 0.2 * want)
+    mag = np.abs(want).max(axis=1, keepdims=True) + 1e-300
+    e_split = float((np.abs(got.cpu().numpy() - want) / mag).max())
+    e_plain = float((np.abs(plain.cpu().numpy() - want) / mag).max())
+    assert e_plain < 2e-6 and e_split < 2e-6, (e_split, e_plain)
+    assert np.isfinite(got.cpu().numpy()).all()
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.mvf_set_mlp_precision(7))
