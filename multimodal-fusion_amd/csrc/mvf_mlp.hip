@@ -494,6 +494,9 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     const bool vec_out = FIXED ? true : A.vec_out != 0;
     // padded output width of layer l
     auto cop_of = [&](int l) { return FIXED ? (((WMASK >> l) & 1) ? 64 : 32) : pad32(A.L[l].cout); };
+#ifdef MVF_CHAIN_STAMP
+    const long long cstart_ = clock64();
+#endif
     extern __shared__ float smem[];
     float *sc = smem;                                   // [3][64] channel scales
     float *sh = sc + MLP_MAX_LAYERS * MLP_MAX_C;        // [3][64] channel shifts
@@ -537,10 +540,43 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     for (int l = (nchunks > 1 ? 1 : 0); l < nlayers; ++l) {
         const mvf_mlp_layer &L = A.L[l];
         const int kin = mlp_wrows(l, L.cin), cop = cop_of(l);
-        for (int idx = tid; idx < kin * cop; idx += MLP_THREADS) {
-            const int k = idx / cop, j = idx - k * cop;
-            smem[(l == 0 ? woff[0] : l == 1 ? woff[1] : woff[2]) + idx] =
-                (k < L.cin && j < L.cout) ? __fmul_rn(L.weight[(size_t)j * L.cin + k], sc[l * MLP_MAX_C + j]) : 0.f;
+        const int cshift = cop > 32 ? 6 : 5, total = (kin >> 2) * cop;     // kin is a multiple of 8
+        const int wbase = l == 0 ? woff[0] : l == 1 ? woff[1] : woff[2];
+        // An item is four consecutive input columns of one output channel: one 16-byte load
+        // where the layer allows it, and the four LDS stores of a wave go to consecutive
+        // addresses.  (Every workgroup of the launch reads the same few kilobytes at the same
+        // time: element-wise reads, 64 cache lines per wave instruction, queue up at one L2
+        // channel.)  Four items of a thread are in flight together.
+        const bool vec = (L.cin & 3) == 0 && ((uintptr_t)L.weight & 15) == 0;
+        for (int i0 = tid; i0 < total; i0 += 4 * MLP_THREADS) {
+            float4 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * MLP_THREADS, k = (idx >> cshift) << 2, j = idx & (cop - 1);
+                w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < total && j < L.cout) {
+                    const float *src = L.weight + (size_t)j * L.cin + k;
+                    if (vec && k + 3 < L.cin) w[u] = ld4(src);
+                    else {
+                        if (k < L.cin) w[u].x = src[0];
+                        if (k + 1 < L.cin) w[u].y = src[1];
+                        if (k + 2 < L.cin) w[u].z = src[2];
+                        if (k + 3 < L.cin) w[u].w = src[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + u * MLP_THREADS, k = (idx >> cshift) << 2, j = idx & (cop - 1);
+                if (idx < total) {
+                    const float sj = sc[l * MLP_MAX_C + j];
+                    float *dst = smem + wbase + k * cop + j;
+                    dst[0] = __fmul_rn(w[u].x, sj);
+                    dst[cop] = __fmul_rn(w[u].y, sj);
+                    dst[2 * cop] = __fmul_rn(w[u].z, sj);
+                    dst[3 * cop] = __fmul_rn(w[u].w, sj);
+                }
+            }
         }
     }
     __syncthreads();
@@ -592,7 +628,17 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     const bool gathered = !POOL && prefetch && (A.a.gather || A.b.gather);
     int nga = 0, ngb = 0;
     if (gathered && (i64)blockIdx.x * MLP_ROWS + stride < A.rows) gather_rows((i64)blockIdx.x * MLP_ROWS + stride, nga, ngb);
+#ifdef MVF_CHAIN_STAMP
+    long long cs_[4] = {0, 0, 0, 0}; int cn_ = 0;
+    const long long cw0_ = wall_clock64(), cc0_ = clock64();
+#define CSTAMP(i_) { const long long n_ = clock64(); cs_[i_] += n_ - clast_; clast_ = n_; }
+#else
+#define CSTAMP(i_) {}
+#endif
     for (i64 base = (i64)blockIdx.x * MLP_ROWS; base < A.rows; base += stride) {
+#ifdef MVF_CHAIN_STAMP
+        long long clast_ = clock64(); ++cn_;
+#endif
         const i64 row = base + wave * 32 + jrow;
         const bool live = row < A.rows;
         floatx16 acc0, acc1;
@@ -685,6 +731,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                     }
             }
         }
+        CSTAMP(0)
         if (POOL) {
             // The pool's per-row loads of this tile are waited for here, before the next
             // tile's rows are requested: that request is conditional, so any later wait for
@@ -765,6 +812,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             acc0 = n0;
             acc1 = n1;
         }
+        CSTAMP(1)
         if (A.dot_out) {
             // The last layer's rows meet one query row each and only the products'
             // sum leaves the kernel (the keys and compatibilities of the attentive
@@ -805,7 +853,13 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                                 smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                                 pseg, pprev, pnext, patt, lane);
     tile_done:;
+        CSTAMP(2)
     }
+#ifdef MVF_CHAIN_STAMP
+    if (blockIdx.x == 9 && tid == 0 && cn_ > 0)
+        printf("chain NL %d grid %d tiles %d: first layer %lld | next layers %lld | epilogue %lld cycles per tile, whole loop %lld, prologue %lld, %.0f MHz\n", NL, (int)gridDim.x, cn_,
+               cs_[0] / cn_, cs_[1] / cn_, cs_[2] / cn_, clock64() - cc0_, cc0_ - cstart_, (double)(clock64() - cc0_) / (double)(wall_clock64() - cw0_) * 100.0);
+#endif
 }
 
 template <int NL, int WMASK, int XQ = 8>
@@ -990,12 +1044,28 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
         const int l = qq >= NQ0, q = l ? qq - NQ0 : qq;
         const mvf_mlp_layer &L = A.L[l];
         const int m = nbo * 32 + (ln & 31), h = ln >> 5;
+        // the 8 input channels of the item are two runs of 4 consecutive ones: 16-byte loads
+        // where the layer allows it (every workgroup reads the same weights at the same time)
         float v[8];
+        const bool vec = (L.cin & 3) == 0 && ((uintptr_t)L.weight & 15) == 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 8 * (q & 1) + j;
-            const int k = l ? 32 * (q >> 1) + acc_channel(r, h) : h * S + 8 * q + j;
-            v[j] = (k < L.cin && m < L.cout) ? __fmul_rn(L.weight[(size_t)m * L.cin + k], sc[l * MLP_MAX_C + m]) : 0.f;
+        for (int half = 0; half < 2; ++half) {
+            const int r = 8 * (q & 1) + 4 * half;
+            const int k = l ? 32 * (q >> 1) + acc_channel(r, h) : h * S + 8 * q + 4 * half;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < L.cout) {
+                const float *src = L.weight + (size_t)m * L.cin + k;
+                if (vec && k + 3 < L.cin) t = ld4(src);
+                else {
+                    if (k < L.cin) t.x = src[0];
+                    if (k + 1 < L.cin) t.y = src[1];
+                    if (k + 2 < L.cin) t.z = src[2];
+                    if (k + 3 < L.cin) t.w = src[3];
+                }
+            }
+            const float sm = sc[l * MLP_MAX_C + m];
+            v[4 * half] = __fmul_rn(t.x, sm); v[4 * half + 1] = __fmul_rn(t.y, sm);
+            v[4 * half + 2] = __fmul_rn(t.z, sm); v[4 * half + 3] = __fmul_rn(t.w, sm);
         }
         Bf3Split sp;
         sp.all(v, false, 1.f);
@@ -1562,9 +1632,11 @@ static int mlp_forward_impl(
     }
     i64 per_cu = (i64)(160 * 1024 / (lds + 1024));
     if (per_cu > 8) per_cu = 8;
+    int forced_per_cu = 0;
 #ifdef MVF_MLP_DEBUG
-    if (const char *e = getenv("MVF_MLP_WGS")) per_cu = atoi(e);
+    if (const char *e = getenv("MVF_MLP_WGS")) forced_per_cu = (int)(per_cu = atoi(e));
 #endif
+    (void)forced_per_cu;
     const i64 want = (rows + MLP_ROWS - 1) / MLP_ROWS, cap = (i64)cus * (per_cu < 1 ? 1 : per_cu > 64 ? 64 : per_cu);
     dim3 grid((unsigned)(want < cap ? want : cap));
     int wmask = 0;
@@ -1574,10 +1646,30 @@ static int mlp_forward_impl(
     const int need = (((cin0 + 1) >> 1) + 3) / 4;
     const int xq = cin0 > MLP_KC ? 8 : need <= 1 ? 1 : need <= 4 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
+    // The grid is what the device holds at once (registers and LDS of the instantiation
+    // decide: looked up once per instantiation and LDS size), every workgroup walking its
+    // share of the tiles: a larger grid runs in rounds, the last of them partly empty, and
+    // stages the weights once more per extra workgroup.
+#define MVF_MLP_RESIDENT(KERNEL_)                                                                \
+    do {                                                                                         \
+        static size_t lds_seen = ~(size_t)0;                                                     \
+        static int occ_seen = 0;                                                                 \
+        if (lds_seen != lds) {                                                                   \
+            int occ = 0;                                                                         \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, KERNEL_, MLP_THREADS, lds) != hipSuccess || occ < 1) \
+                occ = (int)per_cu;                                                               \
+            occ_seen = occ;                                                                      \
+            lds_seen = lds;                                                                      \
+        }                                                                                        \
+        i64 cap_ = (i64)cus * occ_seen;                                                          \
+        if (forced_per_cu > 0) cap_ = (i64)cus * forced_per_cu;                                  \
+        grid = dim3((unsigned)(want < cap_ ? want : cap_));                                      \
+    } while (0)
 #define MVF_MLP_LAUNCH_X(NL_, WM_, XQ_)                                                          \
     do {                                                                                         \
         MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_kernel<NL_, WM_, XQ_>,               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        MVF_MLP_RESIDENT((mlp_chain_kernel<NL_, WM_, XQ_>));                                     \
         hipLaunchKernelGGL((mlp_chain_kernel<NL_, WM_, XQ_>), grid, dim3(MLP_THREADS), lds, st, A); \
     } while (0)
 #define MVF_MLP_LAUNCH(NL_, WM_) MVF_MLP_LAUNCH_X(NL_, WM_, 8)
@@ -1593,6 +1685,7 @@ static int mlp_forward_impl(
     do {                                                                                         \
         MVF_HIP(hipFuncSetAttribute((const void *)mlp_chain_pool_kernel<NL_, WM_, P_, XQ_>,      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        MVF_MLP_RESIDENT((mlp_chain_pool_kernel<NL_, WM_, P_, XQ_>));                            \
         hipLaunchKernelGGL((mlp_chain_pool_kernel<NL_, WM_, P_, XQ_>), grid, dim3(MLP_THREADS), lds, st, A); \
     } while (0)
 #define MVF_MLP_LAUNCH_POOL(NL_, WM_, P_)                                                        \
@@ -1667,6 +1760,7 @@ static int mlp_forward_impl(
     default: MVF_MLP_LAUNCH(3, 7); break;
     }
 #undef MVF_MLP_LAUNCH
+#undef MVF_MLP_RESIDENT
 #undef MVF_MLP_LAUNCH_X
 #undef MVF_MLP_LAUNCH_NARROW
 #undef MVF_MLP_LAUNCH_POOL
