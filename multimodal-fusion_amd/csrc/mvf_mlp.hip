@@ -41,6 +41,9 @@ static int g_mlp_debug;          // host side; bit 0: no output stores, bit 1: n
 #define MLP_DBG(A_) 0          // a compile-time zero: the phase switches vanish from the layer loops
 #endif
 
+#ifdef MVF_CHAIN_STAMP
+__device__ unsigned long long g_chain_span[2048 * 2];   // per workgroup: first / last wall clock (100 MHz)
+#endif
 constexpr int MLP_THREADS = 256;
 constexpr int MLP_WAVES = 4;
 constexpr int MLP_ROWS = 32 * MLP_WAVES;   // rows per workgroup step
@@ -98,6 +101,24 @@ __host__ __device__ __forceinline__ int mlp_wrows(int layer, int cin)
 {
     if (layer == 0) return cin < MLP_KC ? ((cin + 7) & ~7) : MLP_KC;   // whole groups of 4 steps per k-half
     return pad32(cin);
+}
+
+// Issue priority of a wave by its progress through its tiles.  The arbiter of a SIMD serves
+// priority before age, and age alone lets the workgroup that reached a CU first finish its
+// (equal) share in two thirds of the time of the one that came last (137 against 191 us in a
+// launch of 203), after which the CU runs on with ever fewer waves; a wave that is a quarter
+// of its share ahead now yields to the others.  Worth 2-5 % per launch.  (Handing the tiles
+// out on demand instead -- ticket counters shared by the workgroups -- evened the finish times
+// out better, 5 % on the long launches, but the returning atomics of 4096 waves on a few
+// addresses cost the short launches 40 us; with enough counters to avoid that, nothing was
+// left of the balance.)
+__device__ __forceinline__ void prio_by_progress(unsigned done, unsigned share)
+{
+    const unsigned quarter = share ? (4u * done) / share : 3u;
+    if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+    else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+    else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ float mlp_input(const MlpArgs &A, i64 ra, i64 rb, int c)
@@ -496,6 +517,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
     auto cop_of = [&](int l) { return FIXED ? (((WMASK >> l) & 1) ? 64 : 32) : pad32(A.L[l].cout); };
 #ifdef MVF_CHAIN_STAMP
     const long long cstart_ = clock64();
+    const unsigned long long wstart_ = wall_clock64();
 #endif
     extern __shared__ float smem[];
     float *sc = smem;                                   // [3][64] channel scales
@@ -635,7 +657,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
 #else
 #define CSTAMP(i_) {}
 #endif
+    const unsigned my_share = (unsigned)((A.rows - (i64)blockIdx.x * MLP_ROWS + stride - 1) / stride);
+    unsigned my_done = 0;
     for (i64 base = (i64)blockIdx.x * MLP_ROWS; base < A.rows; base += stride) {
+        prio_by_progress(my_done++, my_share);
 #ifdef MVF_CHAIN_STAMP
         long long clast_ = clock64(); ++cn_;
 #endif
@@ -856,6 +881,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         CSTAMP(2)
     }
 #ifdef MVF_CHAIN_STAMP
+    if (tid == 0 && blockIdx.x < 2048) { g_chain_span[blockIdx.x * 2] = wstart_; g_chain_span[blockIdx.x * 2 + 1] = wall_clock64(); }
     if (blockIdx.x == 9 && tid == 0 && cn_ > 0)
         printf("chain NL %d grid %d tiles %d: first layer %lld | next layers %lld | epilogue %lld cycles per tile, whole loop %lld, prologue %lld, %.0f MHz\n", NL, (int)gridDim.x, cn_,
                cs_[0] / cn_, cs_[1] / cn_, cs_[2] / cn_, clock64() - cc0_, cc0_ - cstart_, (double)(clock64() - cc0_) / (double)(wall_clock64() - cw0_) * 100.0);
@@ -1115,7 +1141,10 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
 #else
 #define STAMP(i_) {}
 #endif
+    const unsigned my_share = (unsigned)((A.rows - base + stride - 1) / stride);
+    unsigned my_done = 0;
     for (; base < A.rows; base += stride) {
+        prio_by_progress(my_done++, my_share);
 #ifdef MVF_BF3_STAMP
         long long last_ = clock64(); ++nt_;
 #endif
@@ -1535,6 +1564,13 @@ extern "C" int mvf_set_mlp_precision(int32_t mode)
 }
 
 extern "C" int mvf_get_mlp_precision(void) { return g_mlp_precision; }
+
+#ifdef MVF_CHAIN_STAMP
+extern "C" int mvf_debug_chain_span(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_span), sizeof(unsigned long long) * 2 * n) != hipSuccess;
+}
+#endif
 
 #ifdef MVF_MLP_DEBUG
 extern "C" int mvf_debug_mlp_switch(int mask)
