@@ -107,11 +107,13 @@ __host__ __device__ __forceinline__ int mlp_wrows(int layer, int cin)
 // priority before age, and age alone lets the workgroup that reached a CU first finish its
 // (equal) share in two thirds of the time of the one that came last (137 against 191 us in a
 // launch of 203), after which the CU runs on with ever fewer waves; a wave that is a quarter
-// of its share ahead now yields to the others.  Worth 2-5 % per launch.  (Handing the tiles
-// out on demand instead -- ticket counters shared by the workgroups -- evened the finish times
-// out better, 5 % on the long launches, but the returning atomics of 4096 waves on a few
-// addresses cost the short launches 40 us; with enough counters to avoid that, nothing was
-// left of the balance.)
+// of its share ahead now yields to the others.  Worth about 2 % per launch: with the finish
+// times evened out (166 .. 194 us) the launch is hardly shorter, the CU as a whole gets
+// through its tiles at the same rate either way.  (Also tried: tiles handed out on demand by
+// ticket counters shared between workgroups -- 5 % on the long launches with 32 queues, but
+// the returning atomics of 4096 waves on a few addresses cost the short launches 40 us, and
+// with enough counters to avoid that nothing is left of the balance; larger shares for the
+// workgroups that arrive first -- no change on top of the priorities.)
 __device__ __forceinline__ void prio_by_progress(unsigned done, unsigned share)
 {
     const unsigned quarter = share ? (4u * done) / share : 3u;
