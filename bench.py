@@ -577,7 +577,8 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             measured_frac=None if step_traffic is None
             else step_traffic * n_samples / (ms_step * 1e-3) / HBM_PEAK),
         stage_ms={k: round(v, 4) for k, v in stages.items()})
-    if not depth and not batched:
+    if not depth and not batched and exact:
+        # (the op counter reads the tile bins of the exact pass's workspace layout)
         # The z-buffer lives in LDS: the byte model above charges bytes that never
         # reach HBM.  What bounds the kernel is the issue rate of LDS atomics.
         plan.run()
