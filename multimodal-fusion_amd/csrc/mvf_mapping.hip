@@ -120,6 +120,9 @@ constexpr int NCLS = 8;
 constexpr int ZB_QUEUES = 32;
 constexpr int ZB_QUEUE_STRIDE = 32;
 constexpr int BIN_TAIL = ZB_QUEUE_STRIDE * (ZB_QUEUES + 1);
+// a spare counter of the tail (cleared with it): entries handed out in the verdict buffer of
+// the plain-splat pass
+constexpr int NE_CURSOR_SLOT = 8;
 constexpr int BIN_LDS = 2048;                // LDS histogram entries per block, fused path (points in spatial order)
 constexpr int BIN_LDS_WIDE = 12288;          // single-view entry point: points in any order (48 KB)
 
@@ -851,9 +854,10 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v)
 
 __global__ __launch_bounds__(ZB_THREADS) void zbuffer_count_kernel(
     const TileEntry *__restrict__ entries, const TileDesc *__restrict__ descs,
-    const unsigned *__restrict__ n_desc, i64 pair_capacity, u64 *__restrict__ out)
+    const unsigned *__restrict__ n_desc, i64 pair_capacity, u64 *__restrict__ out, unsigned max_desc)
 {
-    const unsigned nd = *n_desc;
+    // (never past the descriptor list, whatever a workspace of another pass holds there)
+    const unsigned nd = *n_desc < max_desc ? *n_desc : max_desc;
     const int tid = threadIdx.x;
     const unsigned ly = tid & 15, lane = tid & 63;
     const int slot = ly * ZB_QUARTERS + ((ly & 1) ? ZB_QUARTERS - 1 - (tid >> 4) : (tid >> 4));
@@ -1309,15 +1313,27 @@ __device__ __forceinline__ void ne_emit(
     }
 }
 
+// NE_NO_MASKS in moff: the pair's verdicts did not fit the mask buffer.
+constexpr unsigned NE_NO_MASKS = 0xffffffffu;
+
+// FILL = false also stores the verdicts (bitmask, 8 entries = 16 bytes at a time; a pair's
+// entries start at a multiple of 8, reserved per block with one atomic on *mask_cursor) and
+// where they are (moff[i][v]).  FILL = true reads them back: a lane takes one entry (16
+// pixels of a column), a 16-lane prefix sum of the pixel counts gives its place, and it stores
+// its pixels -- one 32-byte read per 16 entries where the first scan reads 16 id-map words per
+// entry.
 template <bool FILL>
 __global__ __launch_bounds__(256) void ne_scan_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
     const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ idmap,
     const mvf_view *__restrict__ views, int W, int Hc, int crop_top, int crop_w, int crop_h, int V,
     unsigned *__restrict__ cnt, const i64 *__restrict__ poff, int16_t *__restrict__ pixels,
-    i64 pix_capacity)
+    i64 pix_capacity, unsigned short *__restrict__ bitmask, unsigned *__restrict__ moff,
+    i64 mask_capacity, unsigned *__restrict__ mask_cursor)
 {
     __shared__ TileEntry list[256];
+    __shared__ unsigned s_ioff[256];
+    __shared__ unsigned s_mbase;
     const int tid = threadIdx.x, v = blockIdx.y;
     const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
     const unsigned n = staged_count[blk];
@@ -1339,6 +1355,16 @@ __global__ __launch_bounds__(256) void ne_scan_kernel(
         nch = ((int)b.yb - (int)b.ya + 15) >> 4;
         return ((int)b.xb - (int)b.xa) * nch;
     };
+    if (!FILL) {
+        // room for the verdicts of the block's pairs: entries of a pair rounded up to 8
+        unsigned mine = 0;
+        if ((unsigned)tid < total) { int nch; mine = ((unsigned)items_of(list[tid], nch) + 7u) & ~7u; }
+        unsigned all;
+        const unsigned before = block_exclusive_scan<unsigned>(mine, all);
+        s_ioff[tid] = before;
+        if (tid == 0) s_mbase = atomicAdd(mask_cursor, all);
+        __syncthreads();
+    }
     // one box per row of 16 lanes
     for (unsigned r = quarter; r < total; r += 16u) {
         const TileEntry b = list[r];
@@ -1347,13 +1373,62 @@ __global__ __launch_bounds__(256) void ne_scan_kernel(
         const unsigned id = (unsigned)b.key;
         const i64 base = FILL ? poff[(size_t)id * V + v] : 0;
         unsigned count = 0;
-        for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
-            NeItems I;
-            const unsigned c = ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
-            if (FILL) ne_emit(I, base + count, ly, pixels, pix_capacity);
-            count += c;
+        if (!FILL) {
+            const i64 mo = (i64)s_mbase + s_ioff[r];
+            const bool keep = mo + (((i64)n_items + 7) & ~(i64)7) <= mask_capacity && (i64)s_mbase + s_ioff[r] < 0xffffffffll;
+            for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
+                NeItems I;
+                count += ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
+                static_assert(NE_ITEMS == 8, "eight 16-bit verdicts are one 16-byte store");
+                if (keep && ly == 0)
+                    *(uint4 *)(bitmask + mo + t0) = make_uint4(I.m[0] | I.m[1] << 16, I.m[2] | I.m[3] << 16,
+                                                               I.m[4] | I.m[5] << 16, I.m[6] | I.m[7] << 16);
+            }
+            if (ly == 0) {
+                cnt[(size_t)id * V + v] = count;
+                moff[(size_t)id * V + v] = keep ? (unsigned)mo : NE_NO_MASKS;
+            }
+            continue;
         }
-        if (!FILL && ly == 0) cnt[(size_t)id * V + v] = count;
+        const unsigned mo = moff[(size_t)id * V + v];
+        if (mo == NE_NO_MASKS) {
+            for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
+                NeItems I;
+                const unsigned c = ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
+                ne_emit(I, base + count, ly, pixels, pix_capacity);
+                count += c;
+            }
+            continue;
+        }
+        const int px0 = (int)b.xa - S.off_x, py0 = (int)b.ya + S.crop_top - S.off_y;
+        for (int t0 = 0; t0 < n_items; t0 += 16) {
+            const int t = t0 + (int)ly;
+            unsigned m = t < n_items ? (unsigned)bitmask[(size_t)mo + t] : 0u;
+            // place of the entry's pixels: prefix sum over the row of 16 lanes
+            const unsigned c = __popc(m);
+            unsigned inc = c;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const unsigned o = __shfl_up(inc, d, 16);
+                if ((int)ly >= d) inc += o;
+            }
+            i64 at = base + count + (inc - c);
+            count += __shfl(inc, 15, 16);
+            if (m) {
+                int cx, cy;
+                if (nch == 1) { cx = t; cy = 0; }
+                else if (nch == 2) { cx = t >> 1; cy = t & 1; }
+                else { cx = t / nch; cy = t - cx * nch; }
+                const int16_t x = (int16_t)(px0 + cx);
+                const int y = py0 + 16 * cy;
+                do {
+                    const int j = __ffs(m) - 1;
+                    m &= m - 1;
+                    if (at < pix_capacity) { pixels[2 * at] = x; pixels[2 * at + 1] = (int16_t)(y + j); }
+                    ++at;
+                } while (m);
+            }
+        }
     }
 }
 
@@ -1843,6 +1918,11 @@ struct MapWorkspace {
     // and first-pixel offsets of the (point, view) pairs [n][V], pixels per block
     unsigned *idmap, *cnt;
     i64 *poff, *block_pix;
+    // ... and the verdicts of the counting scan, 16 pixels of a box column per entry, with the
+    // place of every pair's entries: the second scan reads these instead of the id map
+    unsigned short *bitmask;
+    unsigned *moff;
+    i64 mask_capacity;
     // Vw: views a point can meet (V, or the largest sample of a batched call)
     bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
                i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0, int Vw = 0)
@@ -1871,11 +1951,19 @@ struct MapWorkspace {
         block_sums = ar.take<unsigned>(cdiv(num_points, 256));
         idmap = cnt = nullptr;
         poff = block_pix = nullptr;
+        bitmask = nullptr;
+        moff = nullptr;
+        mask_capacity = 0;
         if (map_pixels > 0) {
             idmap = ar.take<unsigned>((size_t)map_pixels);
             cnt = ar.take<unsigned>((size_t)n * V);
             poff = ar.take<i64>((size_t)n * V);
             block_pix = ar.take<i64>(cdiv(num_points, 256));
+            // half an entry per pixel of the views (C2 needs a third; pairs beyond the
+            // capacity are scanned against the id map a second time)
+            mask_capacity = (map_pixels / 2 + 7) & ~(i64)7;
+            bitmask = ar.take<unsigned short>((size_t)mask_capacity);
+            moff = ar.take<unsigned>((size_t)n * V);
         }
         used = ar.off;
         return ar.ok();
@@ -1918,7 +2006,8 @@ extern "C" int mvf_profile_zbuffer_ops(
         return MVF_E_WORKSPACE;
     }
     hipLaunchKernelGGL(zbuffer_count_kernel, dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, (hipStream_t)stream,
-                       ws.entries, ws.descs, ws.tile_count + ws.ncnt, (i64)pair_capacity, (u64 *)d_out);
+                       ws.entries, ws.descs, ws.tile_count + ws.ncnt, (i64)pair_capacity, (u64 *)d_out,
+                       (unsigned)tiles);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
@@ -2217,7 +2306,8 @@ static int map_images_splat_impl(
     prof_mark("tile_zbuffer", st);
     hipLaunchKernelGGL((ne_scan_kernel<false>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
                        ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
-                       (const i64 *)nullptr, (int16_t *)nullptr, (i64)0);
+                       (const i64 *)nullptr, (int16_t *)nullptr, (i64)0, ws.bitmask, ws.moff, ws.mask_capacity,
+                       ws.tile_count + ncnt + NE_CURSOR_SLOT);
     prof_mark("pixel_count", st);
     dim3 grid_q((unsigned)nb);
     hipLaunchKernelGGL(ne_point_kernel, grid_q, block, 0, st, ws.seen, ws.seen_stride, ws.cnt, V,
@@ -2231,7 +2321,8 @@ static int map_images_splat_impl(
     prof_mark("csr_fill", st);
     hipLaunchKernelGGL((ne_scan_kernel<true>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
                        ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
-                       (const i64 *)ws.poff, pixels, (i64)pix_capacity);
+                       (const i64 *)ws.poff, pixels, (i64)pix_capacity, ws.bitmask, ws.moff, ws.mask_capacity,
+                       (unsigned *)nullptr);
     prof_mark("pixel_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
