@@ -123,7 +123,10 @@ constexpr int BIN_TAIL = ZB_QUEUE_STRIDE * (ZB_QUEUES + 1);
 // a spare counter of the tail (cleared with it): entries handed out in the verdict buffer of
 // the plain-splat pass
 constexpr int NE_CURSOR_SLOT = 8;
-constexpr int BIN_LDS = 2048;                // LDS histogram entries per block, fused path (points in spatial order)
+#ifndef MVF_BIN_LDS
+#define MVF_BIN_LDS 2048
+#endif
+constexpr int BIN_LDS = MVF_BIN_LDS;         // LDS histogram entries per block, fused path (points in spatial order)
 constexpr int BIN_LDS_WIDE = 12288;          // single-view entry point: points in any order (48 KB)
 
 // Raster cost of a (splat, tile) pair: atomic instructions a row of 16 lanes
