@@ -507,7 +507,9 @@ int mvf_mlp_forward(
 
 /* Arithmetic of the layer chains.  mode 1 (default): chains of two layers that are both
  * wider than 32 outputs, on at most 64 aligned and ungathered input columns (E_mod,
- * pooling.py:757, 482-484, and the value encoders of the grouped pools, :272-300), run on
+ * pooling.py:757, 482-484, and the value encoders of the grouped pools, :272-300), and
+ * chains of three layers of at most 32 outputs on at most 64 aligned input columns (the
+ * key / query branches, pooling.py:486-501), run on
  * the bf16 matrix cores with every float32 operand split exactly into three bf16 parts and
  * the six significant part products accumulated in float32: the accuracy of the float32
  * chain (the reference computes these layers with a float32 BLAS, whose summation order is

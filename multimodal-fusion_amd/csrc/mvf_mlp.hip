@@ -1269,6 +1269,233 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
 #endif
 }
 
+// One k-step into one output block: 6 MFMAs, behind each of them two pieces of `fill` (the
+// split of a k-step is 44 / 60 vector instructions: with 6 MFMAs to hide behind, the chain is
+// bound by the vector unit, at about 1.5 times the matrix-pipe time).  `a`: parts 1..3 of this
+// step's weights; those of the next step, at `nxt`, are requested first.
+template <class F>
+__device__ __forceinline__ void bf3_kstep1(
+    uintx4 (&a)[3], const uintx4 *nxt, const uintx4 (&b)[3], floatx16 &n0, F fill)
+{
+    uintx4 t[3];
+    MVF_SB();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = nxt[i * 64];
+    MVF_SB();
+    n0 = mfma_bf16(a[0], b[2], n0); MVF_SB(); fill(0); MVF_SB();
+    n0 = mfma_bf16(a[2], b[0], n0); MVF_SB(); fill(1); MVF_SB();
+    n0 = mfma_bf16(a[1], b[1], n0); MVF_SB(); fill(2); MVF_SB();
+    n0 = mfma_bf16(a[0], b[1], n0); MVF_SB(); fill(3); MVF_SB();
+    n0 = mfma_bf16(a[1], b[0], n0); MVF_SB(); fill(4); MVF_SB();
+    n0 = mfma_bf16(a[0], b[0], n0); MVF_SB(); fill(5); MVF_SB();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a[i] = t[i];
+}
+
+// Three layers of at most 32 outputs each (the key / query chains: two encoder layers and a
+// Linear) on the bf16 matrix cores with split operands, rows stored or met with their query
+// row (dot epilogue, as in mlp_chain_body); first layer of at most 64 input columns from one
+// or two concatenated sources, each with an optional row gather.  LDS image of the weights:
+// [k-step NQ0 + 2 + 2][part 3][lane 64] x 16 bytes.
+template <int NQ0>
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void mlp_narrow3_bf3_kernel(MlpArgs A)
+{
+    extern __shared__ float smem[];
+    float *sc = smem;                                   // [3][64] channel scales
+    float *sh = sc + 3 * MLP_MAX_C;                     // [3][64] channel shifts
+    uintx4 *wl = (uintx4 *)(smem + 6 * MLP_MAX_C);
+    constexpr int S = 8 * NQ0;
+    constexpr int KSTEPS = NQ0 + 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jrow = lane & 31, kh = lane >> 5;
+    const int cin0 = A.L[0].cin;
+    for (int idx = tid; idx < 3 * MLP_MAX_C; idx += MLP_THREADS) {
+        const int l = idx / MLP_MAX_C, j = idx - l * MLP_MAX_C;
+        const mvf_mlp_layer &L = A.L[l];
+        float s = 0.f, t = 0.f;
+        if (j < L.cout) {
+            s = 1.f;
+            if (L.bn_weight) {
+                s = __fdiv_rn(L.bn_weight[j], sqrtf(__fadd_rn(L.bn_var[j], L.bn_eps)));
+                t = __fsub_rn(L.bn_bias[j], __fmul_rn(L.bn_mean[j], s));
+            }
+            if (L.bias) t = __fadd_rn(__fmul_rn(L.bias[j], s), t);
+        }
+        sc[idx] = s;
+        sh[idx] = t;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < KSTEPS * 64; idx += MLP_THREADS) {
+        const int ln = idx & 63, qq = idx >> 6;
+        const int l = qq < NQ0 ? 0 : qq < NQ0 + 2 ? 1 : 2;
+        const int q = l == 0 ? qq : l == 1 ? qq - NQ0 : qq - NQ0 - 2;
+        const mvf_mlp_layer &L = A.L[l];
+        const int m = ln & 31, h = ln >> 5;
+        float v[8];
+        const bool vec = (L.cin & 3) == 0 && ((uintptr_t)L.weight & 15) == 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k = l ? acc_channel(8 * q + 4 * half, h) : h * S + 8 * q + 4 * half;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < L.cout) {
+                const float *src = L.weight + (size_t)m * L.cin + k;
+                if (vec && k + 3 < L.cin) t = ld4(src);
+                else {
+                    if (k < L.cin) t.x = src[0];
+                    if (k + 1 < L.cin) t.y = src[1];
+                    if (k + 2 < L.cin) t.z = src[2];
+                    if (k + 3 < L.cin) t.w = src[3];
+                }
+            }
+            const float sm = sc[l * MLP_MAX_C + m];
+            v[4 * half] = __fmul_rn(t.x, sm); v[4 * half + 1] = __fmul_rn(t.y, sm);
+            v[4 * half + 2] = __fmul_rn(t.z, sm); v[4 * half + 3] = __fmul_rn(t.w, sm);
+        }
+        Bf3Split sp;
+        sp.all(v, false, 1.f);
+        uintx4 *dst = wl + (qq * 3) * 64 + ln;
+        dst[0] = sp.p1; dst[64] = sp.p2; dst[128] = sp.p3;
+    }
+    __syncthreads();
+
+    const i64 stride = (i64)gridDim.x * MLP_ROWS;
+    i64 base = (i64)blockIdx.x * MLP_ROWS;
+    if (base >= A.rows) return;
+    // Source rows of the lane's row in tile `b` (rows past the end read row 0); the gather
+    // indices of a tile are fetched a tile before its rows.
+    auto gather_of = [&](i64 b, int &ga, int &gb) {
+        const i64 r = b + wave * 32 + jrow;
+        ga = gb = 0;
+        if (r < A.rows && A.a.gather) ga = A.a.gather[r];
+        if (r < A.rows && A.b.gather) gb = A.b.gather[r];
+    };
+    float xr[4 * 2 * NQ0], xn[4 * 2 * NQ0];
+    auto load_piece = [&](float *dst, i64 b, int ga, int gb, int q) {
+        i64 r = b + wave * 32 + jrow;
+        if (r >= A.rows) r = 0;
+        const float *pa = A.a.p + (A.a.gather ? (i64)ga : r) * A.a.ld;
+        const float *pb = A.b.p ? A.b.p + (A.b.gather ? (i64)gb : r) * A.b.ld : pa;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int c = kh * S + 8 * q + 4 * u;
+            if (c >= cin0) c = 0;
+            const float4 t = ld4(c < A.a.cols ? pa + c : pb + (c - A.a.cols));
+            dst[8 * q + 4 * u] = t.x; dst[8 * q + 4 * u + 1] = t.y; dst[8 * q + 4 * u + 2] = t.z; dst[8 * q + 4 * u + 3] = t.w;
+        }
+    };
+    int ga0, gb0, ga1, gb1;                             // gather indices: this tile's (prologue only), the next tile's
+    gather_of(base, ga0, gb0);
+    gather_of(base + stride, ga1, gb1);
+#pragma unroll
+    for (int q = 0; q < NQ0; ++q) load_piece(xr, base, ga0, gb0, q);
+    Bf3Split sp;
+    uintx4 cur[3];
+    sp.all(xr, false, 1.f);
+    cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+    const mvf_mlp_layer &L0 = A.L[0], &L1 = A.L[1], &L2 = A.L[2];
+    const float slope0 = L0.act ? L0.slope : 1.f, slope1 = L1.act ? L1.slope : 1.f, slope2 = L2.act ? L2.slope : 1.f;
+    uintx4 aw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) aw[i] = wl[i * 64 + lane];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): no load in flight at the loop entry
+    const unsigned my_share = (unsigned)((A.rows - base + stride - 1) / stride);
+    unsigned my_done = 0;
+    for (; base < A.rows; base += stride) {
+        prio_by_progress(my_done++, my_share);
+        const i64 row = base + wave * 32 + jrow;
+        const bool live = row < A.rows;
+        int lofs = lane;
+        asm volatile("" : "+v"(lofs));
+        const uintx4 *w0 = wl + lofs;
+        // dot epilogue: the row's query index and, behind it, its query values
+        const int qseg = (A.dot_out && live) ? A.dot_seg[row] : 0;
+        // the next tile's rows a whole tile ahead, then the gather indices of the tile after
+#pragma unroll
+        for (int q = 0; q < NQ0; ++q) load_piece(xn, base + stride, ga1, gb1, q);
+        gather_of(base + 2 * stride, ga1, gb1);
+        floatx16 acc, nacc, macc;
+        mlp_init_acc(acc, 0, sh, kh);
+        mlp_init_acc(nacc, 0, sh + MLP_MAX_C, kh);
+        mlp_init_acc(macc, 0, sh + 2 * MLP_MAX_C, kh);
+        // ---- first layer ----
+#pragma unroll
+        for (int q = 0; q < NQ0; ++q) {
+            if (q + 1 < NQ0) {
+                bf3_kstep1(aw, w0 + ((q + 1) * 3) * 64, cur, acc,
+                           [&](int i) { sp.piece(2 * i, 12, xr + 8 * (q + 1), false, 1.f); sp.piece(2 * i + 1, 12, xr + 8 * (q + 1), false, 1.f); });
+                cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+            } else {
+                bf3_kstep1(aw, w0 + ((q + 1) * 3) * 64, cur, acc, [&](int) {});
+            }
+        }
+        float qv[16];
+        if (A.dot_out) {
+            const float *qrow = A.dot_q + (size_t)qseg * A.dot_ldq;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 4 * kh + 8 * g;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < L2.cout) t = ld4(qrow + c);
+                qv[4 * g] = t.x; qv[4 * g + 1] = t.y; qv[4 * g + 2] = t.z; qv[4 * g + 3] = t.w;
+            }
+        }
+        // ---- second layer: k-step 0 = registers 0 .. 7 of the first layer's block ----
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = acc[j];
+        sp.all(v8, true, slope0);
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = acc[8 + j];
+        bf3_kstep1(aw, w0 + ((NQ0 + 1) * 3) * 64, cur, nacc,
+                   [&](int i) { sp.piece(2 * i, 12, v8, true, slope0); sp.piece(2 * i + 1, 12, v8, true, slope0); });
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+        bf3_kstep1(aw, w0 + ((NQ0 + 2) * 3) * 64, cur, nacc, [&](int) {});
+        // ---- third layer ----
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = nacc[j];
+        sp.all(v8, true, slope1);
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = nacc[8 + j];
+        bf3_kstep1(aw, w0 + ((NQ0 + 3) * 3) * 64, cur, macc,
+                   [&](int i) { sp.piece(2 * i, 12, v8, true, slope1); sp.piece(2 * i + 1, 12, v8, true, slope1); });
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+        // every load of this tile has landed by now (see mlp_wide2_bf3_kernel)
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+        bf3_kstep1(aw, w0, cur, macc,
+                   [&](int i) { sp.piece(2 * i, 12, xn, false, 1.f); sp.piece(2 * i + 1, 12, xn, false, 1.f); });
+        cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
+        asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]));
+        // ---- activation of the last layer, then the dot product or the rows ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) macc[r] = max_raw(macc[r], __fmul_rn(macc[r], slope2));
+        if (A.dot_out) {
+            float part = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = 4 * kh + 8 * g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < L2.cout) part = __fadd_rn(part, __fmul_rn(macc[4 * g + e], qv[4 * g + e]));
+            }
+            part = __fadd_rn(part, __shfl_xor(part, 32, 64));
+            if (live && kh == 0) A.dot_out[row] = A.dot_div != 0.f ? __fdiv_rn(part, A.dot_div) : part;
+        } else if (live) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mlp_store4(macc, 0, g, A, true, L2.cout, row, kh);
+        }
+#pragma unroll
+        for (int t = 8; t < 8 * NQ0; ++t) xr[t] = xn[t];
+    }
+}
+
+static size_t bf3_narrow3_lds_bytes(int nq0)
+{
+    return sizeof(float) * 6 * MLP_MAX_C + 16 * (size_t)((nq0 + 4) * 3 * 64);
+}
+
 static size_t bf3_lds_bytes(int nq0, bool pool)
 {
     return sizeof(float) * 4 * MLP_MAX_C + 16 * (size_t)(bf3_layer_vecs(nq0) + bf3_layer_vecs(4)) +
@@ -1732,6 +1959,28 @@ static int mlp_forward_impl(
         else if ((WM_) == 0 && xq == 4) MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 4);                  \
         else MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 8);                                             \
     } while (0)
+    // three narrow layers on at most 64 aligned input columns (rows or the dot epilogue)
+    if (g_mlp_precision != 0 && fixed && nlayers == 3 && wmask == 0 && cin0 <= MLP_KC && !pool_out) {
+        const int nq0 = cin0 <= 16 ? 1 : cin0 <= 32 ? 2 : 4;
+        const size_t lds3 = bf3_narrow3_lds_bytes(nq0);
+#define MVF_BF3N_LAUNCH(NQ_)                                                                     \
+    do {                                                                                         \
+        MVF_HIP(hipFuncSetAttribute((const void *)mlp_narrow3_bf3_kernel<NQ_>,                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));     \
+        static int occ_seen = 0;                                                                 \
+        if (!occ_seen && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_seen, mlp_narrow3_bf3_kernel<NQ_>, MLP_THREADS, lds3) != hipSuccess || occ_seen < 1)) \
+            occ_seen = 2;                                                                        \
+        const i64 cap3 = (i64)cus * occ_seen;                                                    \
+        dim3 grid3((unsigned)(want < cap3 ? want : cap3));                                       \
+        hipLaunchKernelGGL((mlp_narrow3_bf3_kernel<NQ_>), grid3, dim3(MLP_THREADS), lds3, st, A); \
+    } while (0)
+        if (nq0 == 1) MVF_BF3N_LAUNCH(1);
+        else if (nq0 == 2) MVF_BF3N_LAUNCH(2);
+        else MVF_BF3N_LAUNCH(4);
+#undef MVF_BF3N_LAUNCH
+        MVF_LAUNCH_CHECK();
+        return MVF_OK;
+    }
     // two wide layers on at most 64 aligned, ungathered input columns: bf16 matrix cores
     if (g_mlp_precision != 0 && fixed && nlayers == 2 && wmask == 3 && cin0 <= MLP_KC && !gather_a && !gather_b && !dot_out &&
         (!pool_out || (layers[1].cout % 4 == 0 && (uintptr_t)pool_out % 16 == 0))) {

@@ -402,3 +402,58 @@ def test_wide_chain_on_split_bf16_matches_float32_chain(cin, mid, cout, scale):
     assert np.isfinite(got.cpu().numpy()).all()
     with pytest.raises(RuntimeError):
         _lib.check(lib.mvf_set_mlp_precision(7))
+
+
+@pytest.mark.parametrize("cin,w1,w2,w3,dot", [(64, 32, 32, 16, True), (64, 32, 32, 16, False), (32, 32, 32, 32, False),
+                                              (24, 20, 32, 8, True), (8, 32, 16, 12, False), (48, 32, 32, 4, True)])
+def test_narrow_chain_on_split_bf16_matches_float32_chain(cin, w1, w2, w3, dot):
+    """Chains of three layers of at most 32 outputs (two encoder layers and a Linear: the key /
+    query branches) on the bf16 matrix cores with split operands, against the float32 matrix
+    cores and a float64 evaluation: rows from two concatenated sources, the second one gathered
+    per row (gather_csr of a per-segment tensor), rows stored or met with their query row (dot
+    epilogue), a ragged last tile."""
+    from mvfusion import _lib, dense
+    lib = _lib.load()
+    rng = np.random.default_rng(cin * 100 + w3)
+    rows, nseg = 7001, 1803
+    ca = cin // 2 if cin >= 16 else cin
+    xa = (rng.random((rows, ca)) * 2 - 1).astype(np.float32)
+    xb = (rng.random((nseg, cin - ca)) * 2 - 1).astype(np.float32) if cin > ca else None
+    seg = np.sort(rng.integers(0, nseg, rows)).astype(np.int32)
+    torch.manual_seed(cin + w3)
+    mlp = _random_module(pooling.MLP([cin, w1, w2], bias=False), 7).to(DEV).eval()
+    lin = torch.nn.Linear(w2, w3).to(DEV)
+    specs = dense.mlp_layers(mlp) + [dense.linear_layer(lin)]
+    q = (rng.random((nseg, w3)) * 2 - 1).astype(np.float32)
+    kw = dict(dot=(T(q), T(seg), 2.0)) if dot else {}
+
+    def run():
+        if xb is None:
+            return dense.run_layers(specs, T(xa), **kw)
+        return dense.run_layers(specs, T(xa), None, T(xb), T(seg), **kw)
+
+    assert lib.mvf_get_mlp_precision() == 1
+    got = run().cpu().numpy()
+    try:
+        assert lib.mvf_set_mlp_precision(0) == 0
+        plain = run().cpu().numpy()
+    finally:
+        lib.mvf_set_mlp_precision(1)
+    sd = {k: v.double().cpu().numpy() for k, v in mlp.state_dict().items()}
+    want = xa.astype(np.float64) if xb is None else np.concatenate([xa, xb[seg]], 1).astype(np.float64)
+    for i in range(2):
+        bn = f"{i}.1.batch_norm."
+        want = want @ sd[f"{i}.0.weight"].T
+        want = (want - sd[bn + "running_mean"]) / np.sqrt(sd[bn + "running_var"] + mlp[i][1].batch_norm.eps) \
+            * sd[bn + "weight"] + sd[bn + "bias"]
+        want = np.where(want > 0, want, 0.2 * want)
+    want = want @ lin.weight.double().cpu().numpy().T + lin.bias.double().cpu().numpy()
+    if dot:
+        want = (want * q[seg].astype(np.float64)).sum(1, keepdims=True) / 2.0
+        mag = np.abs(want).max() + 1e-300
+    else:
+        mag = np.abs(want).max(axis=1, keepdims=True) + 1e-300
+    assert got.shape == want.shape == plain.shape
+    e_split = float((np.abs(got - want) / mag).max())
+    e_plain = float((np.abs(plain - want) / mag).max())
+    assert e_plain < 3e-6 and e_split < 3e-6, (e_split, e_plain)
