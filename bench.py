@@ -328,13 +328,12 @@ def run_qkv(args, rank, world, device, dist, cpu_leg=True):
                      "flops_per_launch": flops, "kernel_ms": fwd_ms,
                      # flops are those of the float32 layers (2 per multiply-add of the module);
                      # the peak is the float32-input MFMA rate.  The value encoder (E_mod, 58 %
-                     # of them) runs on the bf16 matrix cores with three-way split operands: six
-                     # bf16 products per float32 product, float32 accuracy, 3/8 of the matrix-pipe
-                     # time of the float32 form; the narrow chains stay on the float32 form.
-                     "arithmetic": {"wide_chains": split_mode(), "narrow_chains": "f32 MFMA 32x32x2",
-                                    "bf16_mfma_flops_per_launch": 6 * 2 * Vw * 2 * Cm * Cm
-                                    if split_mode().startswith("bf16") else 0,
-                                    "bf16_peak": 2516.6},
+                     # of them) and the key / query chains run on the bf16 matrix cores with
+                     # three-way split operands: six bf16 products per float32 product, float32
+                     # accuracy, 3/8 of the matrix-pipe time of the float32 form; the two-layer
+                     # narrow chains (mlp_elt_1, mlp_set) stay on the float32 form.
+                     "arithmetic": {"wide_and_three_layer_chains": split_mode(),
+                                    "two_layer_narrow_chains": "f32 MFMA 32x32x2", "bf16_peak": 2516.6},
                      "overlapped": {"ms_per_forward": elapsed / args.steps * 1e3,
                                     "achieved": flops / (elapsed / args.steps) / 1e12,
                                     "frac": flops / (elapsed / args.steps) / MFMA_F32_PEAK},
