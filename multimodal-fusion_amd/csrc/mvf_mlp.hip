@@ -1998,6 +1998,12 @@ static int mlp_forward_impl(
     do {                                                                                         \
         MVF_HIP(hipFuncSetAttribute((const void *)mlp_wide2_bf3_kernel<NQ_, P_>,                 \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));     \
+        /* never more workgroups than the device holds at once (the instantiation with the */   \
+        /* grouped pool's weights fits one per CU only) */                                      \
+        static int occ_seen = 0;                                                                 \
+        if (!occ_seen && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_seen, mlp_wide2_bf3_kernel<NQ_, P_>, MLP_THREADS, lds3) != hipSuccess || occ_seen < 1)) \
+            occ_seen = 1;                                                                        \
+        if (occ_seen < wg_per_cu) grid3 = dim3((unsigned)(want < (i64)cus * occ_seen ? want : (i64)cus * occ_seen)); \
         hipLaunchKernelGGL((mlp_wide2_bf3_kernel<NQ_, P_>), grid3, dim3(MLP_THREADS), lds3, st, A); \
     } while (0)
 #define MVF_BF3_LAUNCH_P(NQ_)                                                                    \

@@ -14,6 +14,7 @@ ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
 Vw = int(ptr[-1])
 x_mod = torch.rand(Vw, 64, device=dev)
 x_map = torch.rand(Vw, 8, device=dev)
+torch.set_grad_enabled(False)       # forward only: the fused inference kernels
 for G in (1, 4):
     torch.manual_seed(0)
     mod = pooling.GroupBimodalCSRPool(in_map=8, in_mod=64, num_groups=G, gating=True).to(dev).eval()
