@@ -1038,7 +1038,7 @@ __host__ __device__ __forceinline__ int bf3_layer_vecs(int nq) { return nq * 2 *
 // of 4, one source or two concatenated ones, 16-byte aligned rows, no row gathers).  NQ0:
 // k-steps of the first layer (16 input columns each).  POOL as in mlp_chain_body.
 template <int NQ0, int POOL>
-__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ __launch_bounds__(MLP_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void mlp_wide2_bf3_kernel(MlpArgs A)
 {
     extern __shared__ float smem[];
@@ -1484,7 +1484,7 @@ void mlp_narrow3_bf3_kernel(MlpArgs A)
             if (live && kh == 0) A.dot_out[row] = A.dot_div != 0.f ? __fdiv_rn(part, A.dot_div) : part;
         } else if (live) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mlp_store4(macc, 0, g, A, true, L2.cout, row, kh);
+            for (int g = 0; g < 4; ++g) mlp_store4(macc, 0, g, A, A.vec_out != 0, L2.cout, row, kh);
         }
 #pragma unroll
         for (int t = 8; t < 8 * NQ0; ++t) xr[t] = xn[t];
@@ -1960,7 +1960,8 @@ static int mlp_forward_impl(
         else MVF_MLP_LAUNCH_POOL_X(NL_, WM_, P_, 8);                                             \
     } while (0)
     // three narrow layers on at most 64 aligned input columns (rows or the dot epilogue)
-    if (g_mlp_precision != 0 && fixed && nlayers == 3 && wmask == 0 && cin0 <= MLP_KC && !pool_out) {
+    // (the output may be of any width and alignment: a score layer of one channel)
+    if (g_mlp_precision != 0 && A.vec_in && mode == 0 && nlayers == 3 && wmask == 0 && cin0 <= MLP_KC && !pool_out) {
         const int nq0 = cin0 <= 16 ? 1 : cin0 <= 32 ? 2 : 4;
         const size_t lds3 = bf3_narrow3_lds_bytes(nq0);
 #define MVF_BF3N_LAUNCH(NQ_)                                                                     \
