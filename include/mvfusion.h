@@ -513,7 +513,9 @@ int mvf_mlp_forward(
  * the bf16 matrix cores with every float32 operand split exactly into three bf16 parts and
  * the six significant part products accumulated in float32: the accuracy of the float32
  * chain (the reference computes these layers with a float32 BLAS, whose summation order is
- * not part of its contract) at 3/8 of its matrix-pipe time.  mode 0: every chain on the
+ * not part of its contract) at 3/8 of its matrix-pipe time.  (Inputs and weights of a
+ * magnitude of 2^127 and above round to infinity in their first bf16 part and give NaN
+ * where the float32 chain gives a large finite value or infinity.)  mode 0: every chain on the
  * float32 matrix cores (exact fmaf chains).  The environment variable
  * MVF_MLP_PRECISION=fp32 selects mode 0 at load time.  Process-wide; no counterpart in the
  * reference. */
