@@ -6,6 +6,7 @@ MFMA layer-chain, attention and row-segment kernels of libmvfusion.so.
 Inference only: the kernels implement eval-mode BatchNorm (running statistics)
 and record no autograd graph.
 """
+import copy
 import ctypes as C
 
 import torch
@@ -136,6 +137,29 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     del keep
 
 
+def aligned_input(specs, x):
+    """(specs, x) with the same product specs(x), on input rows the 16-byte
+    kernels accept.  Rows of at most 64 float32 columns whose width is no
+    multiple of 8 (or whose storage is not 16-byte aligned) are copied into
+    zero-padded rows, and the first layer's weights get zero columns to match
+    (the added products are exact zeros): the aligned kernels, and their pool
+    epilogues, run several times faster than the general one."""
+    if (not specs or not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32
+            or x.dim() != 2 or x.shape[0] == 0 or x.shape[1] > _MAX_C
+            or x.shape[1] != specs[0].cin):
+        return specs, x
+    c = x.shape[1]
+    if c % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        return specs, x
+    cp = (c + 7) // 8 * 8
+    xp = x.new_zeros((x.shape[0], cp))
+    xp[:, :c] = x.detach()
+    first = copy.copy(specs[0])
+    first.weight = torch.nn.functional.pad(specs[0].weight.detach().float(), (0, cp - c))
+    first.cin = cp
+    return [first] + list(specs[1:]), xp
+
+
 def dot_fusable(specs, queries):
     """Can run_layers(..., dot=...) fold the last layer into its dot epilogue?"""
     return (len(specs) >= 1 and specs[-1].cout <= 32 and specs[-1].cout % 4 == 0
@@ -167,6 +191,8 @@ def run_layers(specs, xa, gather_a=None, xb=None, gather_b=None, mode=0, dot=Non
         return t if t.stride(1) == 1 else t.contiguous()
 
     xa, xb = prep(xa), prep(xb)
+    if gather_a is None and xb is None and mode == 0:
+        specs, xa = aligned_input(specs, xa)
     for g in (gather_a, gather_b):
         if g is not None and (g.dtype != torch.int32 or not g.is_cuda):
             raise TypeError("row gathers must be int32 tensors on the HIP device")

@@ -626,7 +626,7 @@ class DeepSetFeat(nn.Module, ABC):
         row per element (run_layers' dot)."""
         if row2seg is None:
             row2seg = _dense.csr_row_segments(ptr, x.shape[0])
-        elt_1 = _dense.mlp_layers(self.mlp_elt_1)
+        elt_1, x = _dense.aligned_input(_dense.mlp_layers(self.mlp_elt_1), x)
         if self.pool == ['max'] and _dense.pool_fusable(elt_1, x, 1):
             # the rows and their per-segment maximum out of one launch
             x1, x_max = _dense.layers_with_segment_max(elt_1, x, ptr, row2seg)
@@ -794,7 +794,7 @@ class GroupBimodalCSRPool(_AttentivePool):
         ptr = _device_ptr(x_mod, csr_idx)
         row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
         score = [_dense.linear_layer(self.E_score)]
-        e_mod = _dense.mlp_layers(self.E_mod)
+        e_mod, x_mod = _dense.aligned_input(_dense.mlp_layers(self.E_mod), x_mod)
         fuse_pool = (not (self.save_last or self.use_mod)
                      and _dense.pool_fusable(e_mod, x_mod, self.num_groups))
         if not fuse_pool:
@@ -903,7 +903,7 @@ class QKVBimodalCSRPool(_AttentivePool):
         # values : V x F_mod.  Unless the encoded values are asked for (save_last,
         # mixed keys / queries) they are produced last, inside the launch that sums
         # them per point (_dense.pooled_layers).
-        e_mod = _dense.mlp_layers(self.E_mod)
+        e_mod, x_mod = _dense.aligned_input(_dense.mlp_layers(self.E_mod), x_mod)
         fuse_pool = (not (self.save_last or self.use_mod_q or self.use_mod_k)
                      and _dense.pool_fusable(e_mod, x_mod, self.num_groups))
         if not fuse_pool:

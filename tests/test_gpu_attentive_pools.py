@@ -460,3 +460,54 @@ def test_narrow_chain_on_split_bf16_matches_float32_chain(cin, w1, w2, w3, dot):
     e_split = float((np.abs(got - want) / mag).max())
     e_plain = float((np.abs(plain - want) / mag).max())
     assert e_plain < 3e-6 and e_split < 3e-6, (e_split, e_plain)
+
+
+@pytest.mark.parametrize("cin,widths,offset", [(6, (64, 64), 0), (2, (32, 32), 0), (13, (32, 32, 16), 0),
+                                               (8, (64, 64), 1), (3, (8, 8), 0)])
+def test_unaligned_input_rows_take_the_aligned_kernels(cin, widths, offset):
+    """Input rows whose width is no multiple of 8, or whose storage is not 16-byte aligned (a view
+    that starts one float into a buffer), are padded with zero columns (dense.aligned_input)
+    and run through the same kernels as aligned rows: against a float64 evaluation, and the
+    DeepSetFeat encoder on such rows against the unfused evaluation of its parts."""
+    from mvfusion import dense
+    rng = np.random.default_rng(cin * 10 + len(widths))
+    rows = 4099
+    base = torch.from_numpy((rng.random(rows * cin + offset) * 2 - 1).astype(np.float32)).to(DEV)
+    x = base[offset:].view(rows, cin)
+    mlp = _random_module(pooling.MLP([cin, *widths], bias=False), 11).to(DEV).eval()
+    specs = dense.mlp_layers(mlp)
+    padded_specs, padded_x = dense.aligned_input(specs, x)
+    assert padded_x.shape[1] % 8 == 0 and padded_x.data_ptr() % 16 == 0
+    assert padded_specs[0].cin == padded_x.shape[1] and specs[0].cin == cin
+    assert torch.equal(padded_x[:, :cin], x) and float(padded_x[:, cin:].abs().sum()) == 0.0
+    got = dense.run_layers(specs, x).cpu().numpy()
+    sd = {k: v.double().cpu().numpy() for k, v in mlp.state_dict().items()}
+    want = x.double().cpu().numpy()
+    for i in range(len(widths)):
+        bn = f"{i}.1.batch_norm."
+        want = want @ sd[f"{i}.0.weight"].T
+        want = (want - sd[bn + "running_mean"]) / np.sqrt(sd[bn + "running_var"] + mlp[i][1].batch_norm.eps) \
+            * sd[bn + "weight"] + sd[bn + "bias"]
+        want = np.where(want > 0, want, 0.2 * want)
+    mag = np.maximum(np.abs(want).max(axis=1, keepdims=True), 0.1 * np.abs(want).max())
+    assert got.shape == want.shape
+    assert float((np.abs(got - want) / mag).max()) < 3e-6
+
+    # the set encoder on rows of that width: the fused launches (rows + segment maximum, gather
+    # + concatenation) against its parts run one by one
+    d_out = 32
+    enc = _random_module(pooling.DeepSetFeat(cin, d_out, use_num=True), 13).to(DEV).eval()
+    counts = np.minimum(rng.poisson(2, 1500), 9)
+    assert counts.sum() <= rows
+    ptr_np = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    n = int(ptr_np[-1])
+    ptr = torch.from_numpy(ptr_np).to(DEV)
+    xs = x[:n]
+    out = enc(xs, ptr)
+    x1 = dense.run_layers(dense.mlp_layers(enc.mlp_elt_1), xs)
+    from mvfusion.pooling import segment_csr, gather_csr, _set_num
+    x_set = torch.cat([segment_csr(x1, ptr, reduce="max"), _set_num(ptr).view(-1, 1)], 1)
+    x_set = dense.run_layers(dense.mlp_layers(enc.mlp_set), x_set)
+    ref = dense.run_layers(dense.mlp_layers(enc.mlp_elt_2), torch.cat([x1, gather_csr(x_set, ptr)], 1))
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) < 1e-5 * scale
