@@ -405,6 +405,37 @@ int mvf_segment_softmax_csr_backward(
     const float *grad_out, const float *y, int32_t G, const int64_t *ptr, int64_t nseg,
     int32_t scaling, float *grad_src, void *stream);
 
+/* ----------------------------------------------------------------------
+ * Differentiable tail of a dense layer: nn.BatchNorm1d + LeakyReLU on float32
+ * rows z [rows][C] (contiguous), as the MLP blocks of
+ * core/common_modules/base_modules.py:38-48 apply them behind their Linear
+ * (FastBatchNorm1d :131-156 on 2D input is nn.BatchNorm1d).
+ *
+ * forward: training != 0 -> batch statistics (biased variance), and the
+ *   running statistics (may be NULL) move by `momentum` towards the batch mean
+ *   and the unbiased batch variance; training == 0 -> running statistics.
+ *   y = act((z - mean) * invstd * weight + bias), act = LeakyReLU(slope) when
+ *   act != 0, identity otherwise; weight / bias may be NULL (1 / 0).
+ *   save_mean / save_invstd [C] receive the statistics used (for backward).
+ * backward: grad_z, and grad_weight / grad_bias [C] (either may be NULL), from
+ *   grad_y, the forward's input z and its saved statistics; the activation's
+ *   sign is recomputed from z.  training must be the forward's.
+ * Column sums are taken in float64 in a fixed order: results are the same on
+ * every run.  workspace: mvf_batch_norm_act_workspace_bytes(C) bytes (the
+ * forward needs it in train mode only).
+ * ---------------------------------------------------------------------- */
+size_t mvf_batch_norm_act_workspace_bytes(int32_t C);
+int mvf_batch_norm_act_forward(
+    const float *z, int64_t rows, int32_t C, const float *weight, const float *bias,
+    float *running_mean, float *running_var, int32_t training, float momentum, float eps,
+    int32_t act, float slope, float *y, float *save_mean, float *save_invstd,
+    void *workspace, size_t workspace_bytes, void *stream);
+int mvf_batch_norm_act_backward(
+    const float *grad_y, const float *z, int64_t rows, int32_t C, const float *weight, const float *bias,
+    const float *save_mean, const float *save_invstd, int32_t training, int32_t act, float slope,
+    float *grad_z, float *grad_weight, float *grad_bias,
+    void *workspace, size_t workspace_bytes, void *stream);
+
 /* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
 int mvf_gather_csr(
     const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,

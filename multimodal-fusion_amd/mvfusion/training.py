@@ -5,9 +5,11 @@ nothing requiring a gradient) run through the fused MFMA layer-chain and
 attention kernels (``dense.py``), which implement BatchNorm with running
 statistics and record no graph.  In ``.train()``, and in ``.eval()`` whenever an
 input or a parameter requires a gradient, the pools are composed here from
-differentiable pieces instead (BatchNorm follows the module's mode): the dense layers (Linear, BatchNorm1d with batch
-statistics, LeakyReLU) are torch modules on the HIP device, the CSR operations
-are this package's kernels wrapped in ``torch.autograd.Function``
+differentiable pieces instead (BatchNorm follows the module's mode): the Linear
+of a dense layer is a library GEMM (torch), its BatchNorm1d + LeakyReLU tail
+one pair of this package's kernels forward and one backward
+(``batch_norm_act``), and the CSR operations are this package's kernels, all
+wrapped in ``torch.autograd.Function``
 (``pooling.segment_csr`` / ``gather_csr`` / ``segment_softmax_csr``).  The
 computation follows modules/multimodal/pooling.py: ``DeepSetFeat.forward``
 :658-681, ``MinMaxDiffSetFeat.forward`` :577-597, ``MLPSetFeat.forward``
@@ -18,13 +20,94 @@ import math
 
 import torch
 
+from . import _lib as L
 from . import pooling as P
 
 
+class _BatchNormAct(torch.autograd.Function):
+    """BatchNorm1d (+ LeakyReLU) of float32 rows on the kernels
+    mvf_batch_norm_act_forward / _backward: two passes over the rows forward,
+    two backward; only the layer's input is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, rm, rv, eps, slope, batch_stats, factor):
+        lib = L.load()
+        z = z.detach().contiguous()
+        rows, C = z.shape
+        dev = z.device
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty_like(z)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        nbytes = lib.mvf_batch_norm_act_workspace_bytes(C)
+        ws = L.workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_batch_norm_act_forward(
+                L.ptr(z), rows, C, L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), int(batch_stats),
+                float(factor), float(eps), int(slope is not None),
+                0.0 if slope is None else float(slope), L.ptr(y), L.ptr(mean), L.ptr(invstd),
+                L.ptr(ws), nbytes, L.stream_ptr(dev)))
+        ctx.save_for_backward(z, w, b, mean, invstd)
+        ctx.slope, ctx.batch_stats = slope, bool(batch_stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        lib = L.load()
+        z, w, b, mean, invstd = ctx.saved_tensors
+        rows, C = z.shape
+        dev = z.device
+        grad_y = grad_y.contiguous()
+        gz = torch.empty_like(z)
+        gw = torch.empty(C, dtype=torch.float32, device=dev) if w is not None and ctx.needs_input_grad[1] else None
+        gb = torch.empty(C, dtype=torch.float32, device=dev) if b is not None and ctx.needs_input_grad[2] else None
+        nbytes = lib.mvf_batch_norm_act_workspace_bytes(C)
+        ws = L.workspace(nbytes, dev)
+        slope = ctx.slope
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_batch_norm_act_backward(
+                L.ptr(grad_y), L.ptr(z), rows, C, L.ptr(w), L.ptr(b), L.ptr(mean), L.ptr(invstd),
+                int(ctx.batch_stats), int(slope is not None), 0.0 if slope is None else float(slope),
+                L.ptr(gz), L.ptr(gw), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr(dev)))
+        return gz, gw, gb, None, None, None, None, None, None
+
+
+def batch_norm_act(z, bn, act):
+    """``act(bn(z))`` for an ``nn.BatchNorm1d`` (train or eval mode, running
+    statistics and ``num_batches_tracked`` updated as the module does) followed
+    by a LeakyReLU, on this package's kernels when z is a float32 [rows, C]
+    tensor on the HIP device; other inputs and activations take the modules."""
+    fused_act = isinstance(act, torch.nn.LeakyReLU)
+    if not (z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and z.shape[0] > 0
+            and isinstance(bn, torch.nn.BatchNorm1d)
+            and all(t is None or (t.is_cuda and t.dtype == torch.float32)
+                    for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var))):
+        return act(bn(z))
+    batch_stats = bn.training or bn.running_mean is None
+    factor = 0.0
+    if batch_stats:
+        if z.shape[0] < 2:
+            raise ValueError(
+                f"Expected more than 1 value per channel when training, got input size {tuple(z.shape)}")
+        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            factor = (1.0 / float(bn.num_batches_tracked)) if bn.momentum is None else bn.momentum
+    # running statistics: updated in train mode, read in eval mode, unused by an eval-mode
+    # module that tracks none (it normalises with batch statistics)
+    use_running = bn.running_mean is not None and (bn.training or not batch_stats)
+    y = _BatchNormAct.apply(z, bn.weight, bn.bias,
+                            bn.running_mean if use_running else None,
+                            bn.running_var if use_running else None, bn.eps,
+                            float(act.negative_slope) if fused_act else None, batch_stats, factor)
+    return y if fused_act else act(y)
+
+
 def mlp(seq, x):
-    """MLP of base_modules.py:38-48: per block Linear, BatchNorm1d, activation."""
+    """MLP of base_modules.py:38-48: per block Linear (a library GEMM), then
+    BatchNorm1d and the activation in one pair of kernels."""
     for block in seq:
-        x = block[2](block[1].batch_norm(block[0](x)))
+        x = batch_norm_act(block[0](x), block[1].batch_norm, block[2])
     return x
 
 

@@ -1,0 +1,42 @@
+"""One training step (forward + backward) of QKVBimodalCSRPool at C3 size, with the
+BatchNorm1d + LeakyReLU tails of the dense layers on this library's kernels
+(training.batch_norm_act) and on the torch modules."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, "multimodal-fusion_amd")
+from mvfusion import pooling, training
+
+dev = "cuda:0"
+rng = np.random.default_rng(3)
+N = 500000
+counts = np.minimum(rng.poisson(4, N), 32)
+ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).to(dev)
+Vw = int(ptr[-1])
+x_main = torch.rand(N, 32, device=dev, requires_grad=True)
+x_mod = torch.rand(Vw, 64, device=dev, requires_grad=True)
+x_map = torch.rand(Vw, 8, device=dev, requires_grad=True)
+torch.manual_seed(0)
+mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=64, out_mod=64).to(dev).train()
+own = training.batch_norm_act
+
+
+def step():
+    out = mod(x_main, x_mod, x_map, ptr)
+    out.sum().backward()
+
+
+for name, fn in (("kernels", own), ("torch modules", lambda z, bn, act: act(bn(z))), ("kernels", own)):
+    training.batch_norm_act = fn
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / 10:.2f} ms per training step ({Vw} rows), "
+          f"peak memory {torch.cuda.max_memory_allocated() / 2**20:.0f} MiB")
+    torch.cuda.reset_peak_memory_stats()

@@ -197,3 +197,73 @@ def test_heuristic_pool_and_eval_mode_calls_are_differentiable():
         fused = qkv(x_main, xm, x_map, ptr)
     assert not fused.requires_grad
     torch.testing.assert_close(got.detach(), fused, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,C,train,affine,track,slope", [
+    (5003, 64, True, True, True, 0.2), (5003, 64, False, True, True, 0.2), (777, 13, True, True, True, 0.2),
+    (2, 8, True, True, True, 0.01), (4099, 1, True, True, True, 0.2), (300, 1040, True, True, True, 0.2),
+    (301, 257, True, True, True, None), (1500, 32, True, False, True, 0.2), (1500, 32, True, True, False, 0.2),
+    (1500, 32, False, True, False, 0.2), (100003, 16, True, True, True, 0.2)])
+def test_batch_norm_act_kernels_match_the_modules(rows, C, train, affine, track, slope):
+    """BatchNorm1d + LeakyReLU behind a dense layer's Linear on this library's kernels
+    (training.batch_norm_act) against the torch modules evaluated in float64: output, the three
+    gradients, running statistics and the batch counter; batch and running statistics, column
+    counts off the 16-byte path and beyond one block's width, a mean far from zero (the variance
+    is a difference of float64 sums; not in the cases of a few rows, where the float32 rounding of
+    the saved mean alone exceeds the tolerance), no affine terms, no tracked statistics."""
+    from mvfusion import training
+    torch.manual_seed(rows + C)
+    bn = torch.nn.BatchNorm1d(C, affine=affine, track_running_stats=track, momentum=0.1).cuda()
+    if affine:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    if track:
+        with torch.no_grad():
+            bn.running_mean.uniform_(-1, 1)
+            bn.running_var.uniform_(0.5, 2.0)
+    ref = torch.nn.BatchNorm1d(C, affine=affine, track_running_stats=track, momentum=0.1).cuda().double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn.train(train)
+    ref.train(train)
+    act = torch.nn.LeakyReLU(slope) if slope is not None else torch.nn.Identity()
+    z = (torch.randn(rows, C, device="cuda") * torch.linspace(0.5, 3.0, C, device="cuda")
+         + torch.linspace(-1.0, 1.0, C, device="cuda") * (40.0 if rows >= 500 else 1.0)).requires_grad_(True)
+    wgt = torch.randn(rows, C, device="cuda")
+    y = training.batch_norm_act(z, bn, act)
+    (y * wgt).sum().backward()
+    zd = z.detach().double().requires_grad_(True)
+    yd = act(ref(zd))
+    (yd * wgt.double()).sum().backward()
+    assert y.dtype == torch.float32 and y.shape == (rows, C)
+    assert close(y.detach().cpu().numpy(), yd.detach().cpu().numpy(), 2e-6)
+    if rows >= 100:
+        assert close(z.grad.cpu().numpy(), zd.grad.cpu().numpy(), 1e-5)
+    else:
+        # with a handful of rows the input gradient is what is left after the batch terms cancel
+        # most of the incoming gradient: compared on the scale of the terms that cancel
+        invstd = 1.0 / torch.sqrt(zd.detach().var(0, unbiased=False) + ref.eps)
+        scale = float((wgt.abs().max(0).values.double() * invstd).max()) * (1.5 if affine else 1.0)
+        assert float((z.grad.double() - zd.grad).abs().max()) <= 1e-5 * scale
+    if affine:
+        # (the float32 rounding of the saved mean shifts every normalised value of a column alike)
+        assert close(bn.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), 1e-5)
+        assert close(bn.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), 2e-6)
+    if track:
+        assert close(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), 1e-6)
+        assert close(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), 1e-6)
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == (1 if train else 0)
+    # the same call again returns the same bits (fixed summation order)
+    bn2 = torch.nn.BatchNorm1d(C, affine=affine, track_running_stats=track, momentum=0.1).cuda().train(train)
+    bn2.load_state_dict(bn.state_dict())
+    y1 = training.batch_norm_act(z.detach(), bn2, act)
+    bn2.load_state_dict(bn.state_dict())
+    y2 = training.batch_norm_act(z.detach(), bn2, act)
+    assert torch.equal(y1, y2)
+
+
+def test_batch_norm_act_single_row_in_train_mode_raises():
+    from mvfusion import training
+    bn = torch.nn.BatchNorm1d(8).cuda().train()
+    with pytest.raises(ValueError):
+        training.batch_norm_act(torch.zeros(1, 8, device="cuda"), bn, torch.nn.LeakyReLU(0.2))
