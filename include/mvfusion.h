@@ -436,6 +436,18 @@ int mvf_batch_norm_act_backward(
     float *grad_z, float *grad_weight, float *grad_bias,
     void *workspace, size_t workspace_bytes, void *stream);
 
+/* out[a][b] = sum over r of x[r][a] * y[r][b] (x: [rows][A], row stride ldx; y:
+ * [rows][B], row stride ldy; out: [A][B], row stride ldo; float32): the weight
+ * gradient of a torch.nn.Linear, grad_weight = grad_out^T . input, for the
+ * Linear layers of the pools' MLPs and projections (base_modules.py:38-48,
+ * pooling.py:406-452), whose reduction runs over every view of every point.
+ * float32 matrix cores, partial sums folded in a fixed order (the same bits on
+ * every run).  workspace: mvf_xty_workspace_bytes() bytes. */
+size_t mvf_xty_workspace_bytes(void);
+int mvf_xty(
+    const float *x, int32_t ldx, int32_t A, const float *y, int32_t ldy, int32_t B, int64_t rows,
+    float *out, int32_t ldo, void *workspace, size_t workspace_bytes, void *stream);
+
 /* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
 int mvf_gather_csr(
     const float *src, int32_t C, const int64_t *ptr, int64_t nseg, int64_t rows,

@@ -6,10 +6,11 @@ attention kernels (``dense.py``), which implement BatchNorm with running
 statistics and record no graph.  In ``.train()``, and in ``.eval()`` whenever an
 input or a parameter requires a gradient, the pools are composed here from
 differentiable pieces instead (BatchNorm follows the module's mode): the Linear
-of a dense layer is a library GEMM (torch), its BatchNorm1d + LeakyReLU tail
-one pair of this package's kernels forward and one backward
-(``batch_norm_act``), and the CSR operations are this package's kernels, all
-wrapped in ``torch.autograd.Function``
+of a dense layer is a library GEMM (torch) for its output and input gradient
+and this package's ``mvf_xty`` for its weight gradient (``linear``), its
+BatchNorm1d + LeakyReLU tail one pair of this package's kernels forward and
+one backward (``batch_norm_act``), and the CSR operations are this package's
+kernels, all wrapped in ``torch.autograd.Function``
 (``pooling.segment_csr`` / ``gather_csr`` / ``segment_softmax_csr``).  The
 computation follows modules/multimodal/pooling.py: ``DeepSetFeat.forward``
 :658-681, ``MinMaxDiffSetFeat.forward`` :577-597, ``MLPSetFeat.forward``
@@ -103,11 +104,59 @@ def batch_norm_act(z, bn, act):
     return y if fused_act else act(y)
 
 
+def xty(x, y):
+    """x^T . y of two float32 [rows, *] tensors on the HIP device (mvf_xty)."""
+    lib = L.load()
+    x, y = x.contiguous(), y.contiguous()
+    dev = x.device
+    out = torch.empty((x.shape[1], y.shape[1]), dtype=torch.float32, device=dev)
+    nbytes = lib.mvf_xty_workspace_bytes()
+    ws = L.workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mvf_xty(L.ptr(x), x.stride(0), x.shape[1], L.ptr(y), y.stride(0), y.shape[1],
+                            x.shape[0], L.ptr(out), out.stride(0), L.ptr(ws), nbytes,
+                            L.stream_ptr(dev)))
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b with library GEMMs for the output and the input gradient
+    (as many rows as the input) and mvf_xty for the weight gradient: a
+    reduction over every row into a few thousand sums, where library GEMMs
+    reach a few percent of the memory bandwidth."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight = ctx.saved_tensors
+        grad_y = grad_y.contiguous()
+        gx = grad_y @ weight if ctx.needs_input_grad[0] else None
+        gw = xty(grad_y, x) if ctx.needs_input_grad[1] else None
+        gb = grad_y.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(lin, x):
+    """``lin(x)`` for an ``nn.Linear`` on float32 [rows, C] device tensors,
+    with the weight gradient on this package's kernel; anything else takes the
+    module."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+            and lin.weight.is_cuda and lin.weight.dtype == torch.float32):
+        return _Linear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 def mlp(seq, x):
-    """MLP of base_modules.py:38-48: per block Linear (a library GEMM), then
-    BatchNorm1d and the activation in one pair of kernels."""
+    """MLP of base_modules.py:38-48: per block Linear (library GEMMs, weight
+    gradient by mvf_xty), then BatchNorm1d and the activation in one pair of
+    kernels."""
     for block in seq:
-        x = batch_norm_act(block[0](x), block[1].batch_norm, block[2])
+        x = batch_norm_act(linear(block[0], x), block[1].batch_norm, block[2])
     return x
 
 
@@ -163,7 +212,7 @@ def group_pool(m, x_main, x_mod, x_map, ptr):
     x_map = map_encoder(m.E_map, x_map, ptr)
     x_mod = mlp(m.E_mod, x_mod)
     x_mix = mlp(m.E_mix, torch.cat([x_map, x_mod], dim=1)) if m.use_mod else x_map
-    comp = m.E_score(x_mix)
+    comp = linear(m.E_score, x_mix)
     x_pool, att, gate = attend(m, x_mod, comp, ptr)
     return x_pool, dict(x_map=x_map, x_mod=x_mod, C=comp, A=att, G=gate)
 
@@ -173,13 +222,13 @@ def qkv_pool(m, x_main, x_mod, x_map, ptr):
     x_map = map_encoder(m.E_map, x_map, ptr)
     x_mod = mlp(m.E_mod, x_mod)
     if m.use_mod_k:
-        keys = m.K(mlp(m.E_mix_K, torch.cat([x_map, x_mod], dim=1)))
+        keys = linear(m.K, mlp(m.E_mix_K, torch.cat([x_map, x_mod], dim=1)))
     else:
-        keys = m.K(x_map)
+        keys = linear(m.K, x_map)
     if m.use_mod_q:
-        queries = m.Q(mlp(m.E_mix_Q, torch.cat([P.gather_csr(x_main, ptr), x_mod], dim=1)))
+        queries = linear(m.Q, mlp(m.E_mix_Q, torch.cat([P.gather_csr(x_main, ptr), x_mod], dim=1)))
     else:
-        queries = P.gather_csr(m.Q(x_main), ptr)
+        queries = P.gather_csr(linear(m.Q, x_main), ptr)
     comp = (keys.view(-1, m.num_groups, m.nc_qk) * queries.view(-1, m.num_groups, m.nc_qk)).sum(dim=2)
     if m.dim_scaling:
         comp = comp / math.sqrt(m.nc_qk)

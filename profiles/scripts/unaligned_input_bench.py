@@ -1,5 +1,5 @@
-import sys, torch, numpy as np
-sys.path.insert(0, "multimodal-fusion_amd")
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "multimodal-fusion_amd"))
 from mvfusion import pooling, dense
 torch.set_grad_enabled(False)
 dev = "cuda:0"

@@ -267,3 +267,32 @@ def test_batch_norm_act_single_row_in_train_mode_raises():
     bn = torch.nn.BatchNorm1d(8).cuda().train()
     with pytest.raises(ValueError):
         training.batch_norm_act(torch.zeros(1, 8, device="cuda"), bn, torch.nn.LeakyReLU(0.2))
+
+
+@pytest.mark.parametrize("rows,A,B", [(100003, 64, 64), (5003, 32, 64), (777, 16, 8), (40, 4, 1), (1, 64, 64),
+                                      (0, 8, 8), (30011, 64, 72), (9001, 130, 33), (2048, 1, 64), (15, 13, 7)])
+def test_xty_weight_gradient_kernel(rows, A, B):
+    """mvf_xty (x^T . y over the rows: the weight gradient of a Linear) against float64, for widths
+    below, at and above one tile of 64 x 64 sums, row counts around the batch of 16 rows, one row,
+    no row; the same bits on a second call; and as the backward of training.linear."""
+    from mvfusion import training
+    g = torch.Generator(device="cuda").manual_seed(rows + A)
+    x = torch.randn(rows, A, device="cuda", generator=g)
+    y = torch.randn(rows, B, device="cuda", generator=g) + 0.5
+    got = training.xty(x, y)
+    want = x.double().T @ y.double()
+    mag = (x.double().abs().T @ y.double().abs()).clamp_min(1e-30)   # what the sums are made of
+    assert got.shape == (A, B)
+    assert float(((got.double() - want).abs() / mag).max()) < 2e-6 if rows else float(got.abs().max()) == 0.0
+    assert torch.equal(got, training.xty(x, y))
+    if rows:
+        lin = torch.nn.Linear(B, A).cuda()
+        inp = y.clone().requires_grad_(True)
+        training.linear(lin, inp).mul(x).sum().backward()
+        ref = torch.nn.Linear(B, A).cuda().double()
+        ref.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+        inp_d = y.double().requires_grad_(True)
+        ref(inp_d).mul(x.double()).sum().backward()
+        assert close(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), 2e-6)
+        assert close(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), 1e-5)
+        assert close(inp.grad.cpu().numpy(), inp_d.grad.cpu().numpy(), 1e-5)
