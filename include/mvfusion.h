@@ -441,8 +441,10 @@ int mvf_batch_norm_act_backward(
  * gradient of a torch.nn.Linear, grad_weight = grad_out^T . input, for the
  * Linear layers of the pools' MLPs and projections (base_modules.py:38-48,
  * pooling.py:406-452), whose reduction runs over every view of every point.
- * float32 matrix cores, partial sums folded in a fixed order (the same bits on
- * every run).  workspace: mvf_xty_workspace_bytes() bytes. */
+ * y == NULL with B == 1 stands for a column of ones: out[a][0] = sum over r of
+ * x[r][a], the bias gradient.  float32 matrix cores, partial sums folded in a
+ * fixed order (the same bits on every run).  workspace:
+ * mvf_xty_workspace_bytes() bytes. */
 size_t mvf_xty_workspace_bytes(void);
 int mvf_xty(
     const float *x, int32_t ldx, int32_t A, const float *y, int32_t ldy, int32_t B, int64_t rows,

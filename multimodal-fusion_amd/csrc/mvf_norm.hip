@@ -20,7 +20,7 @@ namespace mvf {
 
 constexpr int BN_THREADS = 256;
 constexpr int BN_MAX_BLOCKS = 1024;
-constexpr int BN_FOLD_COLS = 16;        // columns per block of the fold kernel
+constexpr int BN_FOLD_COLS = 4;         // columns per block of the fold kernels
 
 template <int VW> __device__ __forceinline__ void bn_load(const float *p, float (&v)[VW])
 {
@@ -209,8 +209,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_grad_sums_kernel(
     bn_block_fold<VW>(s, q, C, partial);
 }
 
-// Fold of the partial rows, BN_FOLD_COLS columns per block, 16 slices of the partial rows
-// per column folded through LDS in a fixed order.  out0 / out1: the two column sums.
+// Fold of the partial rows: BN_FOLD_COLS columns per block, each by BN_THREADS / BN_FOLD_COLS
+// threads that take interleaved partial rows; their sums are added pairwise through LDS (a
+// fixed tree).  out0 / out1: the two column sums, valid in the thread with owner set.
 __device__ __forceinline__ void bn_fold(const double *partial, int nblk, int C, double &out0, double &out1, bool &owner, int &col)
 {
     __shared__ double red[BN_THREADS][2];
@@ -227,15 +228,16 @@ __device__ __forceinline__ void bn_fold(const double *partial, int nblk, int C, 
     red[t][0] = a;
     red[t][1] = b;
     __syncthreads();
-    owner = slice == 0 && col < C;
-    if (owner) {
-        for (int k = 1; k < SLICES; ++k) {
-            a += red[k * BN_FOLD_COLS + c][0];
-            b += red[k * BN_FOLD_COLS + c][1];
+    for (int half = SLICES / 2; half >= 1; half >>= 1) {
+        if (slice < half) {
+            red[t][0] += red[t + half * BN_FOLD_COLS][0];
+            red[t][1] += red[t + half * BN_FOLD_COLS][1];
         }
+        __syncthreads();
     }
-    out0 = a;
-    out1 = b;
+    owner = slice == 0 && col < C;
+    out0 = red[t][0];
+    out1 = red[t][1];
 }
 
 // Batch statistics from the column sums; running statistics updated as nn.BatchNorm1d does

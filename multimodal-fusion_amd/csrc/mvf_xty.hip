@@ -27,7 +27,7 @@ typedef float xty_acc __attribute__((ext_vector_type(16)));
 template <int NA, int NB>
 __global__ __launch_bounds__(XTY_THREADS) void xty_kernel(
     const float *__restrict__ x, int ldx, int A, const float *__restrict__ y, int ldy, int B,
-    i64 rows, i64 rows_per_wave, float *__restrict__ partial)
+    i64 rows, i64 rows_per_wave, int y_ones, float *__restrict__ partial)
 {
     __shared__ float fold[NA * NB * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(XTY_THREADS) void xty_kernel(
 #pragma unroll
             for (int i = 0; i < NA; ++i) xa[buf][u][i] = x[row * ldx + xo[i]];
 #pragma unroll
-            for (int i = 0; i < NB; ++i) yb[buf][u][i] = y[row * ldy + yo[i]];
+            for (int i = 0; i < NB; ++i) yb[buf][u][i] = y_ones ? 1.0f : y[row * ldy + yo[i]];
         }
     };
     auto multiply = [&](int buf) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(XTY_THREADS) void xty_kernel(
 #pragma unroll
         for (int i = 0; i < NA; ++i) { a[i] = x[rr * ldx + xo[i]]; a[i] = ok ? a[i] : 0.0f; }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { b[i] = y[rr * ldy + yo[i]]; b[i] = ok ? b[i] : 0.0f; }
+        for (int i = 0; i < NB; ++i) { b[i] = y_ones ? 1.0f : y[rr * ldy + yo[i]]; b[i] = ok ? b[i] : 0.0f; }
 #pragma unroll
         for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -120,21 +120,31 @@ __global__ __launch_bounds__(XTY_THREADS) void xty_kernel(
     for (int at = threadIdx.x; at < NA * NB * 16 * 64; at += XTY_THREADS) p[at] = fold[at];
 }
 
-// out[a][b] = sum of the workgroups' partial sums, in workgroup order (float64 running sum).
-__global__ __launch_bounds__(256) void xty_fold_kernel(
+// out[a][b] = sum of the workgroups' partial sums.  A block folds 32 consecutive accumulator
+// slots: 8 slices of the workgroups per slot (float64 running sums in workgroup order), then the
+// slices in order through LDS.
+constexpr int XTY_FOLD_SLOTS = 32, XTY_FOLD_SLICES = 8;
+
+__global__ __launch_bounds__(XTY_FOLD_SLOTS * XTY_FOLD_SLICES) void xty_fold_kernel(
     const float *__restrict__ partial, int nwg, int NA, int NB, int A, int B, float *__restrict__ out, int ldo)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= A * B) return;
-    const int a = idx / B, b = idx - a * B;
-    const int m = a & 31, n = b & 31;
-    // accumulator register and lane that hold (m, n) of a 32 x 32 block
-    const int e = (m & 3) + 4 * (m >> 3), lane = n + 32 * ((m >> 2) & 1);
-    const size_t at = (size_t)(((a >> 5) * NB + (b >> 5)) * 16 + e) * 64 + lane;
+    __shared__ double red[XTY_FOLD_SLICES][XTY_FOLD_SLOTS];
+    const int slot = threadIdx.x % XTY_FOLD_SLOTS, slice = threadIdx.x / XTY_FOLD_SLOTS;
+    const int at = blockIdx.x * XTY_FOLD_SLOTS + slot;          // < NA * NB * 1024 (grid is exact)
     const size_t stride = (size_t)NA * NB * 16 * 64;
+    const int per = (nwg + XTY_FOLD_SLICES - 1) / XTY_FOLD_SLICES;
+    const int k1 = min(nwg, (slice + 1) * per);
     double s = 0.0;
-    for (int k = 0; k < nwg; ++k) s += (double)partial[k * stride + at];
-    out[(size_t)a * ldo + b] = (float)s;
+    for (int k = slice * per; k < k1; ++k) s += (double)partial[k * stride + at];
+    red[slice][slot] = s;
+    __syncthreads();
+    if (slice != 0) return;
+    for (int k = 1; k < XTY_FOLD_SLICES; ++k) s += red[k][slot];
+    // (block, accumulator register e, lane) of the slot -> (a, b)
+    const int lane = at & 63, e = (at >> 6) & 15, blk = at >> 10;
+    const int a = (blk / NB) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+    const int b = (blk % NB) * 32 + (lane & 31);
+    if (a < A && b < B) out[(size_t)a * ldo + b] = (float)s;
 }
 
 }  // namespace mvf
@@ -152,7 +162,8 @@ extern "C" int mvf_xty(
 {
     MVF_REQUIRE(A >= 1 && B >= 1 && rows >= 0, "xty: A and B must be positive, rows non-negative");
     MVF_REQUIRE(out && ldo >= B, "xty: null output or ldo < B");
-    MVF_REQUIRE(rows == 0 || (x && y && ldx >= A && ldy >= B), "xty: null input or a row stride below the width");
+    MVF_REQUIRE(rows == 0 || (x && ldx >= A && (y ? ldy >= B : B == 1)),
+                "xty: null input, a row stride below the width, or B != 1 without y");
     MVF_REQUIRE(workspace && workspace_bytes >= mvf_xty_workspace_bytes(), "xty: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
@@ -171,16 +182,16 @@ extern "C" int mvf_xty(
         for (int b0 = 0; b0 < B; b0 += 64) {
             const int At = A - a0 < 64 ? A - a0 : 64, Bt = B - b0 < 64 ? B - b0 : 64;
             const int NA = At > 32 ? 2 : 1, NB = Bt > 32 ? 2 : 1;
-            const float *xt = x + a0, *yt = y + b0;
+            const float *xt = x + a0, *yt = y ? y + b0 : x;
 #define MVF_XTY_LAUNCH(NA_, NB_)                                                                  \
     hipLaunchKernelGGL((xty_kernel<NA_, NB_>), dim3((unsigned)nwg), dim3(XTY_THREADS), 0, st, xt, \
-                       (int)ldx, At, yt, (int)ldy, Bt, (i64)rows, rpw, partial)
+                       (int)ldx, At, yt, (int)ldy, Bt, (i64)rows, rpw, y ? 0 : 1, partial)
             if (NA == 1 && NB == 1) MVF_XTY_LAUNCH(1, 1);
             else if (NA == 1) MVF_XTY_LAUNCH(1, 2);
             else if (NB == 1) MVF_XTY_LAUNCH(2, 1);
             else MVF_XTY_LAUNCH(2, 2);
 #undef MVF_XTY_LAUNCH
-            hipLaunchKernelGGL(xty_fold_kernel, dim3(cdiv((i64)At * Bt, 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL(xty_fold_kernel, dim3(NA * NB * 1024 / XTY_FOLD_SLOTS), dim3(XTY_FOLD_SLOTS * XTY_FOLD_SLICES), 0, st,
                                (const float *)partial, (int)nwg, NA, NB, At, Bt,
                                out + (size_t)a0 * ldo + b0, (int)ldo);
         }

@@ -104,11 +104,21 @@ def batch_norm_act(z, bn, act):
     return y if fused_act else act(y)
 
 
-def xty(x, y):
-    """x^T . y of two float32 [rows, *] tensors on the HIP device (mvf_xty)."""
+def xty(x, y=None):
+    """x^T . y of two float32 [rows, *] tensors on the HIP device (mvf_xty);
+    without y the column sums of x, [A, 1]."""
     lib = L.load()
-    x, y = x.contiguous(), y.contiguous()
+    x = x.contiguous()
     dev = x.device
+    if y is None:
+        out = torch.empty((x.shape[1], 1), dtype=torch.float32, device=dev)
+        nbytes = lib.mvf_xty_workspace_bytes()
+        ws = L.workspace(nbytes, dev)
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_xty(L.ptr(x), x.stride(0), x.shape[1], None, 0, 1, x.shape[0],
+                                L.ptr(out), 1, L.ptr(ws), nbytes, L.stream_ptr(dev)))
+        return out
+    y = y.contiguous()
     out = torch.empty((x.shape[1], y.shape[1]), dtype=torch.float32, device=dev)
     nbytes = lib.mvf_xty_workspace_bytes()
     ws = L.workspace(nbytes, dev)
@@ -137,7 +147,7 @@ class _Linear(torch.autograd.Function):
         grad_y = grad_y.contiguous()
         gx = grad_y @ weight if ctx.needs_input_grad[0] else None
         gw = xty(grad_y, x) if ctx.needs_input_grad[1] else None
-        gb = grad_y.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        gb = xty(grad_y).view(-1) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 

@@ -24,6 +24,8 @@ plain = (lambda z, bn, act: act(bn(z)), lambda lin, x: lin(x))
 
 
 def step():
+    mod.zero_grad(set_to_none=True)
+    x_main.grad = x_mod.grad = x_map.grad = None
     out = mod(x_main, x_mod, x_map, ptr)
     out.sum().backward()
 

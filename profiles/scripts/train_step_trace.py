@@ -18,5 +18,7 @@ x_map = torch.rand(Vw, 8, device=dev, requires_grad=True)
 torch.manual_seed(0)
 mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=64, out_mod=64).to(dev).train()
 for _ in range(5):
+    mod.zero_grad(set_to_none=True)
+    x_main.grad = x_mod.grad = x_map.grad = None
     mod(x_main, x_mod, x_map, ptr).sum().backward()
 torch.cuda.synchronize()

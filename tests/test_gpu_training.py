@@ -285,6 +285,10 @@ def test_xty_weight_gradient_kernel(rows, A, B):
     assert got.shape == (A, B)
     assert float(((got.double() - want).abs() / mag).max()) < 2e-6 if rows else float(got.abs().max()) == 0.0
     assert torch.equal(got, training.xty(x, y))
+    sums = training.xty(x)
+    assert sums.shape == (A, 1)
+    if rows:
+        assert float(((sums.view(-1).double() - x.double().sum(0)).abs() / x.double().abs().sum(0).clamp_min(1e-30)).max()) < 2e-6
     if rows:
         lin = torch.nn.Linear(B, A).cuda()
         inp = y.clone().requires_grad_(True)
