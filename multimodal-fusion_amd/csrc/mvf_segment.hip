@@ -527,6 +527,74 @@ static int pick_layout(const void *p0, const void *p1, int C, int &vec, int &lpr
     return 0;
 }
 
+// Attention-weighted sum of the rows of every segment (the pooling step of the attentive
+// pools, pooling.py:289-296, 519-526, with a graph): out[s][c] = sum over the rows r of s of
+// x[r][c] * att[r][group of c], G groups of C / G adjacent channels, rows folded in order.
+// A thread owns 4 channels of one segment.
+__global__ __launch_bounds__(256) void weighted_segment_sum_kernel(
+    const float *__restrict__ x, const float *__restrict__ att, int C, int G,
+    const i64 *__restrict__ ptr, i64 nseg, float *__restrict__ out)
+{
+    const unsigned cv = (unsigned)(C / 4);
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nseg * cv) return;
+    const i64 seg = e / cv;
+    const unsigned c4 = (unsigned)(e - seg * cv);
+    const unsigned g = c4 * 4u / (unsigned)(C / G);
+    const i64 a = ptr[seg], b = ptr[seg + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 *xs = (const float4 *)x;
+    for (i64 r = a; r < b; r += 2) {
+        const bool two = r + 1 < b;
+        const float4 v0 = xs[(size_t)r * cv + c4];
+        const float w0 = att[(size_t)r * G + g];
+        float4 v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float w1 = 0.f;
+        if (two) {
+            v1 = xs[(size_t)(r + 1) * cv + c4];
+            w1 = att[(size_t)(r + 1) * G + g];
+        }
+        acc.x = __fadd_rn(acc.x, __fmul_rn(v0.x, w0)); acc.y = __fadd_rn(acc.y, __fmul_rn(v0.y, w0));
+        acc.z = __fadd_rn(acc.z, __fmul_rn(v0.z, w0)); acc.w = __fadd_rn(acc.w, __fmul_rn(v0.w, w0));
+        if (two) {
+            acc.x = __fadd_rn(acc.x, __fmul_rn(v1.x, w1)); acc.y = __fadd_rn(acc.y, __fmul_rn(v1.y, w1));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(v1.z, w1)); acc.w = __fadd_rn(acc.w, __fmul_rn(v1.w, w1));
+        }
+    }
+    ((float4 *)out)[e] = acc;
+}
+
+// Its gradients: grad_x[r][c] = grad_out[seg r][c] * att[r][g(c)] and grad_att[r][g] = sum over
+// the channels of g of grad_out[seg r][c] * x[r][c].  A thread owns 4 channels of one row; the
+// C / (4 G) threads of a group are adjacent lanes of one wave (a power of two) and add their
+// partial sums by xor shuffles (a fixed tree).
+__global__ __launch_bounds__(256) void weighted_segment_sum_backward_kernel(
+    const float *__restrict__ grad_out, const float *__restrict__ x, const float *__restrict__ att,
+    int C, int G, const int *__restrict__ row2seg, i64 rows,
+    float *__restrict__ grad_x, float *__restrict__ grad_att)
+{
+    const unsigned cv = (unsigned)(C / 4);
+    const unsigned lg = cv / (unsigned)G;               // lanes per group
+    const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < rows * cv;                    // (whole rows per wave: cv divides 64)
+    const i64 r = live ? e / cv : 0;
+    const unsigned c4 = live ? (unsigned)(e - r * cv) : 0u;
+    const unsigned g = c4 / lg;
+    float dot = 0.f;
+    if (live) {
+        const i64 seg = row2seg[r];
+        const float4 go = ((const float4 *)grad_out)[(size_t)seg * cv + c4];
+        const float4 xv = ((const float4 *)x)[(size_t)r * cv + c4];
+        const float w = att[(size_t)r * G + g];
+        if (grad_x)
+            ((float4 *)grad_x)[e] = make_float4(__fmul_rn(go.x, w), __fmul_rn(go.y, w), __fmul_rn(go.z, w), __fmul_rn(go.w, w));
+        dot = __fadd_rn(__fadd_rn(__fmul_rn(go.x, xv.x), __fmul_rn(go.y, xv.y)),
+                        __fadd_rn(__fmul_rn(go.z, xv.z), __fmul_rn(go.w, xv.w)));
+    }
+    for (unsigned d = 1; d < lg; d <<= 1) dot = __fadd_rn(dot, __shfl_xor(dot, (int)d, 64));
+    if (live && grad_att && (c4 & (lg - 1)) == 0) grad_att[(size_t)r * G + g] = dot;
+}
+
 }  // namespace mvf
 
 using namespace mvf;
@@ -593,6 +661,44 @@ extern "C" int mvf_segment_csr_backward(
     default: MVF_SB(MVF_REDUCE_MAX); break;
     }
 #undef MVF_SB
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+static bool weighted_sum_shape_ok(int C, int G)
+{
+    if (C < 4 || G < 1 || C % 4 != 0 || C % G != 0 || (C / G) % 4 != 0) return false;
+    const int cv = C / 4, lg = cv / G;
+    return cv <= 64 && (cv & (cv - 1)) == 0 && (lg & (lg - 1)) == 0;
+}
+
+extern "C" int mvf_weighted_segment_sum(
+    const float *x, const float *att, int32_t C, int32_t G, const int64_t *ptr, int64_t nseg,
+    float *out, void *stream)
+{
+    MVF_REQUIRE(weighted_sum_shape_ok(C, G),
+                "weighted_segment_sum: C / 4 and C / (4 G) must be powers of two, C <= 256 (got C=%d G=%d)", C, G);
+    MVF_REQUIRE(nseg >= 0 && out && ptr, "weighted_segment_sum: null argument");
+    MVF_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0, "weighted_segment_sum: x and out must be 16-byte aligned");
+    if (nseg == 0) return MVF_OK;
+    hipLaunchKernelGGL(weighted_segment_sum_kernel, dim3(cdiv(nseg * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, att, C, G, (const i64 *)ptr, (i64)nseg, out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
+}
+
+extern "C" int mvf_weighted_segment_sum_backward(
+    const float *grad_out, const float *x, const float *att, int32_t C, int32_t G,
+    const int32_t *row2seg, int64_t rows, float *grad_x, float *grad_att, void *stream)
+{
+    MVF_REQUIRE(weighted_sum_shape_ok(C, G),
+                "weighted_segment_sum_backward: C / 4 and C / (4 G) must be powers of two, C <= 256 (got C=%d G=%d)", C, G);
+    MVF_REQUIRE(rows >= 0 && grad_out && row2seg, "weighted_segment_sum_backward: null argument");
+    MVF_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)grad_out % 16 == 0 && (uintptr_t)grad_x % 16 == 0,
+                "weighted_segment_sum_backward: x, grad_out and grad_x must be 16-byte aligned");
+    if (rows == 0) return MVF_OK;
+    hipLaunchKernelGGL(weighted_segment_sum_backward_kernel, dim3(cdiv(rows * (C / 4), 256)), dim3(256), 0,
+                       (hipStream_t)stream, grad_out, x, att, C, G, row2seg, (i64)rows, grad_x, grad_att);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -205,12 +205,64 @@ def map_encoder(m, x, ptr):
     return mlp(m.mlp, x)
 
 
+class _WeightedSegmentSum(torch.autograd.Function):
+    """segment_csr(x * expand_group_feat(att), ptr, 'sum') in one pass over x,
+    and both gradients in one pass (mvf_weighted_segment_sum / _backward)."""
+
+    @staticmethod
+    def forward(ctx, x, att, ptr, num_groups):
+        lib = L.load()
+        x, att = x.detach().contiguous(), att.detach().contiguous()
+        dev = x.device
+        nseg = ptr.shape[0] - 1
+        out = torch.empty((nseg, x.shape[1]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_weighted_segment_sum(L.ptr(x), L.ptr(att), x.shape[1], num_groups,
+                                                 L.ptr(ptr), nseg, L.ptr(out), L.stream_ptr(dev)))
+        ctx.save_for_backward(x, att, ptr)
+        ctx.num_groups = num_groups
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = L.load()
+        x, att, ptr = ctx.saved_tensors
+        dev = x.device
+        rows, C = x.shape
+        grad_out = grad_out.contiguous()
+        row2seg = P._dense.csr_row_segments(ptr, rows)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gatt = torch.empty_like(att) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dev):
+            L.check(lib.mvf_weighted_segment_sum_backward(
+                L.ptr(grad_out), L.ptr(x), L.ptr(att), C, ctx.num_groups, L.ptr(row2seg), rows,
+                L.ptr(gx), L.ptr(gatt), L.stream_ptr(dev)))
+        return gx, gatt, None, None
+
+
+def weighted_segment_sum(x, att, ptr, num_groups):
+    """Sum over the rows of every segment of ``x * expand_group_feat(att)``
+    (pooling.py:289-296, 519-526): one kernel forward and one backward when the
+    channels split into equal groups of a power-of-two multiple of 4 channels
+    (and every row belongs to a segment, as in the pools); the composition of
+    ``expand_group_feat`` and ``segment_csr`` otherwise."""
+    C = x.shape[1]
+    cv = C // 4
+    ok = (x.is_cuda and x.dtype == torch.float32 and att.dtype == torch.float32 and x.dim() == 2
+          and x.shape[0] > 0 and C % 4 == 0 and C % num_groups == 0 and (C // num_groups) % 4 == 0
+          and cv <= 64 and cv & (cv - 1) == 0
+          and (cv // num_groups) & (cv // num_groups - 1) == 0
+          and att.numel() == x.shape[0] * num_groups and ptr.dtype == torch.int64)
+    if not ok:
+        return P.segment_csr(x * P.expand_group_feat(att, num_groups, C), ptr, reduce='sum')
+    return _WeightedSegmentSum.apply(x, att, ptr, num_groups)
+
+
 def attend(m, x_mod, comp, ptr):
     """Softmax of the compatibilities over the views of a point, attention-
     weighted sum of the values, optional gate from the best compatibility."""
     att = P.segment_softmax_csr(comp, ptr, scaling=m.group_scaling)
-    x_pool = P.segment_csr(x_mod * P.expand_group_feat(att, m.num_groups, m.out_mod), ptr,
-                           reduce='sum')
+    x_pool = weighted_segment_sum(x_mod, att, ptr, m.num_groups)
     gate = None
     if m.G is not None:
         gate = m.G(P.segment_csr(comp, ptr, reduce='max'))

@@ -300,3 +300,31 @@ def test_xty_weight_gradient_kernel(rows, A, B):
         assert close(lin.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), 2e-6)
         assert close(lin.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), 1e-5)
         assert close(inp.grad.cpu().numpy(), inp_d.grad.cpu().numpy(), 1e-5)
+
+
+@pytest.mark.parametrize("C,G", [(64, 1), (64, 4), (32, 8), (16, 1), (128, 2), (8, 2), (48, 3), (64, 64)])
+def test_weighted_segment_sum_and_its_gradients(C, G):
+    """training.weighted_segment_sum (the attention-weighted sum of the views of a point, one
+    kernel forward and one backward) against the composition it replaces evaluated in float64;
+    empty segments, one long segment, shapes that fall back to the composition (48 / 3: the
+    group is no power-of-two multiple of 4 channels; one channel per group)."""
+    from mvfusion import pooling, training
+    rng = np.random.default_rng(C + G)
+    counts = np.minimum(rng.poisson(3, 3000), 20)
+    counts[17] = 300
+    ptr = T(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).cuda()
+    rows = int(counts.sum())
+    x = torch.randn(rows, C, device="cuda").requires_grad_(True)
+    att = torch.rand(rows, G, device="cuda").requires_grad_(True)
+    wgt = torch.randn(len(counts), C, device="cuda")
+    out = training.weighted_segment_sum(x, att, ptr, G)
+    (out * wgt).sum().backward()
+    xd, ad = x.detach().double().requires_grad_(True), att.detach().double().requires_grad_(True)
+    seg = torch.repeat_interleave(torch.arange(len(counts), device="cuda"), T(counts).cuda())
+    full = xd * (ad.repeat_interleave(C // G, dim=1) if G < C else ad)
+    ref = torch.zeros(len(counts), C, dtype=torch.float64, device="cuda").index_add_(0, seg, full)
+    (ref * wgt.double()).sum().backward()
+    assert close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6)
+    assert close(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 2e-6)
+    assert close(att.grad.cpu().numpy(), ad.grad.cpu().numpy(), 2e-6)
+    assert float(out[T(counts == 0).cuda()].abs().sum()) == 0.0
