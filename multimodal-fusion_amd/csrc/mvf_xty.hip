@@ -120,10 +120,10 @@ __global__ __launch_bounds__(XTY_THREADS) void xty_kernel(
     for (int at = threadIdx.x; at < NA * NB * 16 * 64; at += XTY_THREADS) p[at] = fold[at];
 }
 
-// out[a][b] = sum of the workgroups' partial sums.  A block folds 32 consecutive accumulator
-// slots: 8 slices of the workgroups per slot (float64 running sums in workgroup order), then the
-// slices in order through LDS.
-constexpr int XTY_FOLD_SLOTS = 32, XTY_FOLD_SLICES = 8;
+// out[a][b] = sum of the workgroups' partial sums.  A block folds 16 consecutive accumulator
+// slots: 16 slices of the workgroups per slot (float64 running sums in workgroup order), then
+// the slices in order through LDS.
+constexpr int XTY_FOLD_SLOTS = 16, XTY_FOLD_SLICES = 16;
 
 __global__ __launch_bounds__(XTY_FOLD_SLOTS * XTY_FOLD_SLICES) void xty_fold_kernel(
     const float *__restrict__ partial, int nwg, int NA, int NB, int A, int B, float *__restrict__ out, int ldo)
