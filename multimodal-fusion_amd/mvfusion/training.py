@@ -129,23 +129,42 @@ def xty(x, y=None):
     return out
 
 
+class _Weights:
+    """What dense.LayerSpec reads of an nn.Linear."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.out_features, self.in_features = weight.shape
+
+
+def _product(x, weight, bias):
+    """x W^T + b over many rows: one launch of the float32 MFMA layer-chain
+    kernel with a single plain layer for the widths of the pools (it streams the
+    rows at a higher rate than the library GEMM does for these shapes), the
+    library GEMM otherwise."""
+    if max(weight.shape) <= 256 and x.shape[0] >= 4096:
+        w = weight.detach()
+        return P._dense.run_layers([P._dense.LayerSpec(_Weights(w if w.is_contiguous() else w.contiguous(), bias))], x)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b with library GEMMs for the output and the input gradient
-    (as many rows as the input) and mvf_xty for the weight gradient: a
-    reduction over every row into a few thousand sums, where library GEMMs
-    reach a few percent of the memory bandwidth."""
+    """y = x W^T + b: the output and the input gradient (as many rows as the
+    input) by ``_product``, the weight gradient by mvf_xty: a reduction over
+    every row into a few thousand sums, where library GEMMs reach a few percent
+    of the memory bandwidth."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return _product(x, weight, bias)
 
     @staticmethod
     def backward(ctx, grad_y):
         x, weight = ctx.saved_tensors
         grad_y = grad_y.contiguous()
-        gx = grad_y @ weight if ctx.needs_input_grad[0] else None
+        gx = _product(grad_y, weight.t(), None) if ctx.needs_input_grad[0] else None
         gw = xty(grad_y, x) if ctx.needs_input_grad[1] else None
         gb = xty(grad_y).view(-1) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
