@@ -249,6 +249,33 @@ def split_mode():
         else "f32 MFMA 32x32x2"
 
 
+def qkv_training_step(mod, x_main, x_mod, x_map, ptr, Vw):
+    """One training step (forward + backward with batch statistics) of the C3 module and rows
+    (left out of the profiler runs, --no-extras: their kernel statistics are the forward's)."""
+    mod.train()
+    xs = [t.clone().requires_grad_(True) for t in (x_main, x_mod, x_map)]
+
+    def train_step():
+        mod.zero_grad(set_to_none=True)
+        for t in xs:
+            t.grad = None
+        mod(xs[0], xs[1], xs[2], ptr).sum().backward()
+
+    for _ in range(3):
+        train_step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(10):
+        train_step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    mod.eval()
+    ms = ev[0].elapsed_time(ev[1]) / 10
+    return {"what": "QKVBimodalCSRPool in .train(): forward + backward to inputs and parameters, "
+                    "BatchNorm batch statistics, same rows as the forward",
+            "ms_per_step": ms, "steps": 10, "points_views_per_s": Vw / (ms * 1e-3)}
+
+
 def run_qkv(args, rank, world, device, dist, cpu_leg=True):
     """C3: the attentive pool on synthetic CSR groups; one step = one forward."""
     from mvfusion import pooling
@@ -340,31 +367,8 @@ def run_qkv(args, rank, world, device, dist, cpu_leg=True):
                      "hbm": {"algorithmic_bytes": bytes_,
                              "frac": bytes_ / (fwd_ms * 1e-3) / HBM_PEAK}},
     }
-    # one training step (forward + backward with batch statistics) of the same module and rows
-    mod.train()
-    xs = [t.clone().requires_grad_(True) for t in (x_main, x_mod, x_map)]
-
-    def train_step():
-        mod.zero_grad(set_to_none=True)
-        for t in xs:
-            t.grad = None
-        mod(xs[0], xs[1], xs[2], ptr).sum().backward()
-
-    for _ in range(3):
-        train_step()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ev[0].record()
-    for _ in range(10):
-        train_step()
-    ev[1].record()
-    torch.cuda.synchronize()
-    mod.eval()
-    line["training_step"] = {
-        "what": "QKVBimodalCSRPool in .train(): forward + backward to inputs and parameters, "
-                "BatchNorm batch statistics, same rows as the forward",
-        "ms_per_step": ev[0].elapsed_time(ev[1]) / 10, "steps": 10,
-        "points_views_per_s": Vw / (ev[0].elapsed_time(ev[1]) / 10 * 1e-3)}
-    del xs
+    if not args.no_extras:
+        line["training_step"] = qkv_training_step(mod, x_main, x_mod, x_map, ptr, Vw)
     if cpu_leg:
         # the oracle's numpy restatement of the same forward on the first 50k points
         orc = oracle()
