@@ -603,7 +603,7 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             frac=B["total"] * n_samples / (ms_step * 1e-3) / HBM_PEAK,
             measured_traffic_per_step=step_traffic,
             measured_frac=None if step_traffic is None
-            else step_traffic * n_samples / (ms_step * 1e-3) / HBM_PEAK),
+            else step_traffic / (ms_step * 1e-3) / HBM_PEAK),     # (a step's traffic: all its samples)
         stage_ms={k: round(v, 4) for k, v in stages.items()})
     if not depth and not batched and exact:
         # (the op counter reads the tile bins of the exact pass's workspace layout)
