@@ -4,15 +4,16 @@
 // the reduction runs over millions of rows and the result has at most a few thousand entries.
 //
 // float32 matrix cores (v_mfma_f32_32x32x2_f32): a wave keeps up to 2 x 2 blocks of 32 x 32
-// sums in its accumulators and takes two rows per instruction.  The A operand of a block is x[row][a0 + lane % 32], the B operand
-// y[row][b0 + lane % 32], row = the pair's first row + lane / 32: both are plain dword loads
-// of 128 contiguous bytes per row, straight from global memory (one load per operand block
-// feeds a 64-cycle instruction, so there is nothing to gain from staging in LDS).  Batches of 16
-// or 32 rows are dealt to the waves in turn; a wave has one batch in flight while it multiplies
-// the batch before.  The four waves of a
-// workgroup fold their accumulators through LDS in wave order, every workgroup writes one
-// partial result and a second kernel adds the partials in workgroup order: no atomics, the
-// same bits on every run.  The pass is bound by HBM (4 (A + B) bytes per row).
+// sums in its accumulators and takes two rows per instruction.  The A operand of a block is
+// x[row][a0 + lane % 32], the B operand y[row][b0 + lane % 32], row = the pair's first row +
+// lane / 32: the operands come straight from global memory in the layout the instruction wants,
+// 128 contiguous bytes per row and block (one load per operand block feeds a 64-cycle
+// instruction, so there is nothing to gain from staging in LDS).  Batches of 16 or 32 rows are
+// dealt to the waves in turn; a wave has one batch in flight while it multiplies the batch
+// before.  The four waves of a workgroup fold their accumulators through LDS in wave order,
+// every workgroup writes one partial result and a second kernel adds the partials in workgroup
+// order: no atomics, the same bits on every run.  The pass is bound by HBM (4 (A + B) bytes per
+// row).
 #include "mvf_common.h"
 
 namespace mvf {
