@@ -456,15 +456,15 @@ int mvf_xty(
  * groups of C / G adjacent channels; rows of a segment are folded in order.
  * backward: grad_x[r][c] = grad_out[s(r)][c] * att[r][g(c)] and grad_att[r][g] =
  * sum over the channels of g of grad_out[s(r)][c] * x[r][c] (either may be
- * NULL); row2seg: int32 [rows] (mvf_csr_row_segments); every row belongs to a
- * segment.  Shapes: C / 4 and C / (4 G) powers of two, C <= 256; x, out and the
+ * NULL); row2seg: int32 [rows] (mvf_csr_row_segments), a value outside
+ * [0, nseg) marks a row of no segment: its gradients are zero.  Shapes: C / 4 and C / (4 G) powers of two, C <= 256; x, out and the
  * gradients 16-byte aligned and contiguous. */
 int mvf_weighted_segment_sum(
     const float *x, const float *att, int32_t C, int32_t G, const int64_t *ptr, int64_t nseg,
     float *out, void *stream);
 int mvf_weighted_segment_sum_backward(
     const float *grad_out, const float *x, const float *att, int32_t C, int32_t G,
-    const int32_t *row2seg, int64_t rows, float *grad_x, float *grad_att, void *stream);
+    const int32_t *row2seg, int64_t rows, int64_t nseg, float *grad_x, float *grad_att, void *stream);
 
 /* gather_csr (pooling.py:825-853): out[r] = src[segment of r], [rows][C]. */
 int mvf_gather_csr(

@@ -565,12 +565,13 @@ __global__ __launch_bounds__(256) void weighted_segment_sum_kernel(
 }
 
 // Its gradients: grad_x[r][c] = grad_out[seg r][c] * att[r][g(c)] and grad_att[r][g] = sum over
-// the channels of g of grad_out[seg r][c] * x[r][c].  A thread owns 4 channels of one row; the
+// the channels of g of grad_out[seg r][c] * x[r][c] (zero for a row whose row2seg entry is no
+// segment index).  A thread owns 4 channels of one row; the
 // C / (4 G) threads of a group are adjacent lanes of one wave (a power of two) and add their
 // partial sums by xor shuffles (a fixed tree).
 __global__ __launch_bounds__(256) void weighted_segment_sum_backward_kernel(
     const float *__restrict__ grad_out, const float *__restrict__ x, const float *__restrict__ att,
-    int C, int G, const int *__restrict__ row2seg, i64 rows,
+    int C, int G, const int *__restrict__ row2seg, i64 rows, i64 nseg,
     float *__restrict__ grad_x, float *__restrict__ grad_att)
 {
     const unsigned cv = (unsigned)(C / 4);
@@ -583,7 +584,9 @@ __global__ __launch_bounds__(256) void weighted_segment_sum_backward_kernel(
     float dot = 0.f;
     if (live) {
         const i64 seg = row2seg[r];
-        const float4 go = ((const float4 *)grad_out)[(size_t)seg * cv + c4];
+        // (a row of no segment: zero gradients)
+        const float4 go = seg >= 0 && seg < nseg ? ((const float4 *)grad_out)[(size_t)seg * cv + c4]
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 xv = ((const float4 *)x)[(size_t)r * cv + c4];
         const float w = att[(size_t)r * G + g];
         if (grad_x)
@@ -689,7 +692,7 @@ extern "C" int mvf_weighted_segment_sum(
 
 extern "C" int mvf_weighted_segment_sum_backward(
     const float *grad_out, const float *x, const float *att, int32_t C, int32_t G,
-    const int32_t *row2seg, int64_t rows, float *grad_x, float *grad_att, void *stream)
+    const int32_t *row2seg, int64_t rows, int64_t nseg, float *grad_x, float *grad_att, void *stream)
 {
     MVF_REQUIRE(weighted_sum_shape_ok(C, G),
                 "weighted_segment_sum_backward: C / 4 and C / (4 G) must be powers of two, C <= 256 (got C=%d G=%d)", C, G);
@@ -698,7 +701,7 @@ extern "C" int mvf_weighted_segment_sum_backward(
                 "weighted_segment_sum_backward: x, grad_out and grad_x must be 16-byte aligned");
     if (rows == 0) return MVF_OK;
     hipLaunchKernelGGL(weighted_segment_sum_backward_kernel, dim3(cdiv(rows * (C / 4), 256)), dim3(256), 0,
-                       (hipStream_t)stream, grad_out, x, att, C, G, row2seg, (i64)rows, grad_x, grad_att);
+                       (hipStream_t)stream, grad_out, x, att, C, G, row2seg, (i64)rows, (i64)nseg, grad_x, grad_att);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

@@ -289,10 +289,15 @@ def layers_with_segment_max(specs, x, ptr, row2seg):
     return out, seg
 
 
-def csr_row_segments(ptr, rows):
-    """int32 [rows]: segment index of every row of a CSR pointer array."""
+def csr_row_segments(ptr, rows, outside=None):
+    """int32 [rows]: segment index of every row of a CSR pointer array.  Rows
+    that belong to no segment (before ptr[0], from ptr[-1] on) are left
+    unwritten, or set to `outside` when it is given."""
     lib = L.load()
-    out = torch.empty(rows, dtype=torch.int32, device=ptr.device)
+    if outside is None:
+        out = torch.empty(rows, dtype=torch.int32, device=ptr.device)
+    else:
+        out = torch.full((rows,), int(outside), dtype=torch.int32, device=ptr.device)
     if rows > 0:
         with torch.cuda.device(ptr.device):
             L.check(lib.mvf_csr_row_segments(

@@ -249,13 +249,13 @@ class _WeightedSegmentSum(torch.autograd.Function):
         dev = x.device
         rows, C = x.shape
         grad_out = grad_out.contiguous()
-        row2seg = P._dense.csr_row_segments(ptr, rows)
+        row2seg = P._dense.csr_row_segments(ptr, rows, outside=-1)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gatt = torch.empty_like(att) if ctx.needs_input_grad[1] else None
         with torch.cuda.device(dev):
             L.check(lib.mvf_weighted_segment_sum_backward(
                 L.ptr(grad_out), L.ptr(x), L.ptr(att), C, ctx.num_groups, L.ptr(row2seg), rows,
-                L.ptr(gx), L.ptr(gatt), L.stream_ptr(dev)))
+                ptr.shape[0] - 1, L.ptr(gx), L.ptr(gatt), L.stream_ptr(dev)))
         return gx, gatt, None, None
 
 
@@ -263,7 +263,7 @@ def weighted_segment_sum(x, att, ptr, num_groups):
     """Sum over the rows of every segment of ``x * expand_group_feat(att)``
     (pooling.py:289-296, 519-526): one kernel forward and one backward when the
     channels split into equal groups of a power-of-two multiple of 4 channels
-    (and every row belongs to a segment, as in the pools); the composition of
+    (rows outside every segment get zero gradients); the composition of
     ``expand_group_feat`` and ``segment_csr`` otherwise."""
     C = x.shape[1]
     cv = C // 4

@@ -313,7 +313,8 @@ def test_weighted_segment_sum_and_its_gradients(C, G):
     counts = np.minimum(rng.poisson(3, 3000), 20)
     counts[17] = 300
     ptr = T(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).cuda()
-    rows = int(counts.sum())
+    extra = 5                               # rows behind the last segment: no part in any sum
+    rows = int(counts.sum()) + extra
     x = torch.randn(rows, C, device="cuda").requires_grad_(True)
     att = torch.rand(rows, G, device="cuda").requires_grad_(True)
     wgt = torch.randn(len(counts), C, device="cuda")
@@ -322,9 +323,10 @@ def test_weighted_segment_sum_and_its_gradients(C, G):
     xd, ad = x.detach().double().requires_grad_(True), att.detach().double().requires_grad_(True)
     seg = torch.repeat_interleave(torch.arange(len(counts), device="cuda"), T(counts).cuda())
     full = xd * (ad.repeat_interleave(C // G, dim=1) if G < C else ad)
-    ref = torch.zeros(len(counts), C, dtype=torch.float64, device="cuda").index_add_(0, seg, full)
+    ref = torch.zeros(len(counts), C, dtype=torch.float64, device="cuda").index_add_(0, seg, full[:rows - extra])
     (ref * wgt.double()).sum().backward()
     assert close(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6)
     assert close(x.grad.cpu().numpy(), xd.grad.cpu().numpy(), 2e-6)
     assert close(att.grad.cpu().numpy(), ad.grad.cpu().numpy(), 2e-6)
+    assert float(x.grad[rows - extra:].abs().sum()) == 0.0 and float(att.grad[rows - extra:].abs().sum()) == 0.0
     assert float(out.detach()[T(counts == 0).cuda()].abs().sum()) == 0.0
