@@ -488,6 +488,12 @@ def _device_ptr(x, csr_idx):
         raise RuntimeError(
             "mvfusion pooling runs on a HIP device only: move the features and "
             "the CSR pointers to the GPU (there is no CPU fallback).")
+    if not csr_idx.is_cuda and csr_idx.numel() > 0 and (
+            int(csr_idx[0]) != 0 or int(csr_idx[-1]) != x.shape[0]):
+        # (pointers on the device are not read back: the kernels then only make sure that rows
+        # outside every group cannot make them read out of bounds)
+        raise ValueError(
+            f"CSR pointers cover rows {int(csr_idx[0])}..{int(csr_idx[-1])} of {x.shape[0]} feature rows")
     return csr_idx.to(device=x.device, dtype=torch.int64).contiguous()
 
 
@@ -625,7 +631,7 @@ class DeepSetFeat(nn.Module, ABC):
         fused behind mlp_elt_2, and optionally their dot product with a query
         row per element (run_layers' dot)."""
         if row2seg is None:
-            row2seg = _dense.csr_row_segments(ptr, x.shape[0])
+            row2seg = _dense.csr_row_segments(ptr, x.shape[0], outside=0)
         elt_1, x = _dense.aligned_input(_dense.mlp_layers(self.mlp_elt_1), x)
         if self.pool == ['max'] and _dense.pool_fusable(elt_1, x, 1):
             # the rows and their per-segment maximum out of one launch
@@ -792,7 +798,7 @@ class GroupBimodalCSRPool(_AttentivePool):
             from . import training
             return self._forward_train(training.group_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)
-        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
+        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0], outside=0)
         score = [_dense.linear_layer(self.E_score)]
         e_mod, x_mod = _dense.aligned_input(_dense.mlp_layers(self.E_mod), x_mod)
         fuse_pool = (not (self.save_last or self.use_mod)
@@ -897,7 +903,7 @@ class QKVBimodalCSRPool(_AttentivePool):
             from . import training
             return self._forward_train(training.qkv_pool, x_main, x_mod, x_map, csr_idx)
         ptr = _device_ptr(x_mod, csr_idx)
-        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0])
+        row2seg = _dense.csr_row_segments(ptr, x_mod.shape[0], outside=0)
         k_lin, q_lin = [_dense.linear_layer(self.K)], [_dense.linear_layer(self.Q)]
 
         # values : V x F_mod.  Unless the encoded values are asked for (save_last,
