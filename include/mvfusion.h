@@ -436,6 +436,18 @@ int mvf_batch_norm_act_backward(
     float *grad_z, float *grad_weight, float *grad_bias,
     void *workspace, size_t workspace_bytes, void *stream);
 
+/* y = x W^T (+ bias) for contiguous float32 rows: x [rows][I], weight [O][I]
+ * (torch.nn.Linear layout), bias [O] or NULL, y [rows][O]; I a multiple of 8,
+ * O a multiple of 4, both at most 64 (mvf_linear_rows_supported), x and y
+ * 16-byte aligned.  The output and the input gradient (weight = W^T) of the
+ * Linear layers of the pools' MLPs and projections when a graph is recorded
+ * (base_modules.py:38-48, pooling.py:406-452): a streaming pass on the float32
+ * matrix cores with every row read and written once, in memory order. */
+int mvf_linear_rows_supported(int32_t I, int32_t O);
+int mvf_linear_rows(
+    const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
+    float *y, void *stream);
+
 /* out[a][b] = sum over r of x[r][a] * y[r][b] (x: [rows][A], row stride ldx; y:
  * [rows][B], row stride ldy; out: [A][B], row stride ldo; float32): the weight
  * gradient of a torch.nn.Linear, grad_weight = grad_out^T . input, for the

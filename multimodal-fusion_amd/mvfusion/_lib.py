@@ -112,6 +112,8 @@ _SIGNATURES = {
     "mvf_xty": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I64, _P, _I32, _P, _SZ, _P]),
     "mvf_weighted_segment_sum": (C.c_int, [_P, _P, _I32, _I32, _P, _I64, _P, _P]),
     "mvf_weighted_segment_sum_backward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _I64, _I64, _P, _P, _P]),
+    "mvf_linear_rows_supported": (C.c_int, [_I32, _I32]),
+    "mvf_linear_rows": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _P]),
     "mvf_knn": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "mvf_mapping_occlusion": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _I64, _P, _I32, _P]),
     "mvf_gather_csr": (C.c_int, [_P, _I32, _P, _I64, _I64, _P, _P]),

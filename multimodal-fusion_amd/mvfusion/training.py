@@ -138,14 +138,27 @@ class _Weights:
 
 
 def _product(x, weight, bias):
-    """x W^T + b over many rows: one launch of the float32 MFMA layer-chain
-    kernel with a single plain layer for the widths of the pools (it streams the
-    rows at a higher rate than the library GEMM does for these shapes), the
-    library GEMM otherwise."""
-    if max(weight.shape) <= 256 and x.shape[0] >= 4096:
-        w = weight.detach()
-        return P._dense.run_layers([P._dense.LayerSpec(_Weights(w if w.is_contiguous() else w.contiguous(), bias))], x)
-    return torch.nn.functional.linear(x, weight, bias)
+    """x W^T + b over many rows: the streaming float32 MFMA kernel (mvf_linear_rows)
+    for at most 64 input and output columns, one launch of the layer-chain
+    kernel with a single plain layer for wider ones (both stream the rows at
+    a higher rate than the library GEMM does for these shapes), the library
+    GEMM otherwise."""
+    if max(weight.shape) > 256 or x.shape[0] < 4096:
+        return torch.nn.functional.linear(x, weight, bias)
+    dense = P._dense
+    w = weight.detach()
+    specs, xp = dense.aligned_input(
+        [dense.LayerSpec(_Weights(w if w.is_contiguous() else w.contiguous(), bias))], x.detach())
+    lib = L.load()
+    cout, cin = specs[0].cout, specs[0].cin
+    if not (lib.mvf_linear_rows_supported(cin, cout) and xp.is_contiguous() and xp.data_ptr() % 16 == 0):
+        return dense.run_layers(specs, xp)
+    wp, bp = specs[0].weight.float().contiguous(), None if bias is None else bias.detach().float().contiguous()
+    y = torch.empty((xp.shape[0], cout), dtype=torch.float32, device=xp.device)
+    with torch.cuda.device(xp.device):
+        L.check(lib.mvf_linear_rows(L.ptr(xp), cin, L.ptr(wp), L.ptr(bp), cout, xp.shape[0], L.ptr(y),
+                                    L.stream_ptr(xp.device)))
+    return y
 
 
 class _Linear(torch.autograd.Function):

@@ -330,3 +330,27 @@ def test_weighted_segment_sum_and_its_gradients(C, G):
     assert close(att.grad.cpu().numpy(), ad.grad.cpu().numpy(), 2e-6)
     assert float(x.grad[rows - extra:].abs().sum()) == 0.0 and float(att.grad[rows - extra:].abs().sum()) == 0.0
     assert float(out.detach()[T(counts == 0).cuda()].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cin,cout,bias", [(100003, 64, 64, False), (5003, 8, 32, True), (4099, 32, 16, True),
+                                                (65536, 40, 36, False), (4096, 16, 4, True), (9999, 64, 8, False),
+                                                (31, 24, 64, True), (1, 8, 8, True)])
+def test_linear_rows_streaming_kernel(rows, cin, cout, bias):
+    """mvf_linear_rows (y = x W^T + b in one streaming pass, the Linear outputs and input gradients
+    of the differentiable path) against float64: every supported width class, a ragged last tile,
+    fewer rows than one tile."""
+    from mvfusion import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(rows + cin)
+    x = torch.randn(rows, cin, device="cuda", generator=g)
+    w = torch.randn(cout, cin, device="cuda", generator=g)
+    b = torch.randn(cout, device="cuda", generator=g) if bias else None
+    assert lib.mvf_linear_rows_supported(cin, cout) == 1
+    assert lib.mvf_linear_rows_supported(cin + 1, cout) == 0 and lib.mvf_linear_rows_supported(cin, 65) == 0
+    y = torch.full((rows + 1, cout), 7.0, device="cuda")         # a guard row behind the output
+    _lib.check(lib.mvf_linear_rows(_lib.ptr(x), cin, _lib.ptr(w), _lib.ptr(b), cout, rows, _lib.ptr(y),
+                                   _lib.stream_ptr(x.device)))
+    want = x.double() @ w.double().T + (b.double() if bias else 0.0)
+    mag = x.double().abs() @ w.double().abs().T + 1e-30
+    assert float(((y[:rows].double() - want).abs() / mag).max()) < 1e-6
+    assert float((y[rows] - 7.0).abs().max()) == 0.0
