@@ -421,15 +421,18 @@ int mvf_segment_softmax_csr_backward(
  *   grad_y, the forward's input z and its saved statistics; the activation's
  *   sign is recomputed from z.  training must be the forward's.
  * Column sums are taken in float64 in a fixed order: results are the same on
- * every run.  workspace: mvf_batch_norm_act_workspace_bytes(C) bytes (the
- * forward needs it in train mode only).
+ * every run.  col_sums (may be NULL): n_col_sums partial rows [2][C] of float64
+ * whose sums over the rows are the column sums of z and z * z
+ * (mvf_linear_rows_sums); the forward then does not read z for them.
+ * workspace: mvf_batch_norm_act_workspace_bytes(C) bytes (the forward needs it
+ * in train mode without col_sums only).
  * ---------------------------------------------------------------------- */
 size_t mvf_batch_norm_act_workspace_bytes(int32_t C);
 int mvf_batch_norm_act_forward(
     const float *z, int64_t rows, int32_t C, const float *weight, const float *bias,
     float *running_mean, float *running_var, int32_t training, float momentum, float eps,
     int32_t act, float slope, float *y, float *save_mean, float *save_invstd,
-    void *workspace, size_t workspace_bytes, void *stream);
+    const double *col_sums, int32_t n_col_sums, void *workspace, size_t workspace_bytes, void *stream);
 int mvf_batch_norm_act_backward(
     const float *grad_y, const float *z, int64_t rows, int32_t C, const float *weight, const float *bias,
     const float *save_mean, const float *save_invstd, int32_t training, int32_t act, float slope,
@@ -447,6 +450,15 @@ int mvf_linear_rows_supported(int32_t I, int32_t O);
 int mvf_linear_rows(
     const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
     float *y, void *stream);
+/* The same pass, which also leaves the column sums of y and y * y as
+ * *n_col_sums partial rows [2][O] of float64 in col_sums (a buffer of
+ * mvf_linear_rows_sums_bytes(O) bytes): what mvf_batch_norm_act_forward folds
+ * the batch statistics from (its col_sums argument), so that a train-mode
+ * Linear + BatchNorm1d reads the Linear's output once less. */
+size_t mvf_linear_rows_sums_bytes(int32_t O);
+int mvf_linear_rows_sums(
+    const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
+    float *y, double *col_sums, size_t col_sums_bytes, int32_t *n_col_sums, void *stream);
 
 /* out[a][b] = sum over r of x[r][a] * y[r][b] (x: [rows][A], row stride ldx; y:
  * [rows][B], row stride ldy; out: [A][B], row stride ldo; float32): the weight

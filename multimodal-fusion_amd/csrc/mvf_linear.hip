@@ -22,16 +22,20 @@ constexpr int SL_WAVES = SL_THREADS / 64;
 constexpr int SL_ROWS = 32;                 // rows per tile
 constexpr int SL_MAX_C = 64;
 constexpr int SL_PITCH_MAX = SL_MAX_C * 4 + 16;
+constexpr int SL_MAX_WGS = 256;             // workgroups of a launch (one per compute unit), 4 partial rows each
 
 typedef float sl_acc __attribute__((ext_vector_type(16)));
 typedef float sl_f4 __attribute__((ext_vector_type(4)));
 
 // KQ: 16-byte pieces of a lane half's part of an input row (I = 8 KQ); NO: blocks of 32 output
 // channels.
-template <int KQ, int NO>
+// STATS: the column sums of y and y * y over the wave's rows as well (float32 per lane over its
+// tiles, float64 across the lanes), one partial row [2][O] per wave: what BatchNorm's batch
+// statistics are folded from (mvf_batch_norm_act_forward's col_sums).
+template <int KQ, int NO, bool STATS>
 __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
     const float *__restrict__ x, int I, const float *__restrict__ W, const float *__restrict__ bias, int O,
-    i64 rows, float *__restrict__ y)
+    i64 rows, float *__restrict__ y, double *__restrict__ col_sums)
 {
     // one region per wave: a tile of x on its way in, then the tile of y on its way out (the
     // LDS operations of a wave execute in order)
@@ -91,6 +95,14 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
         }
     };
 
+    float sum1[STATS ? NO : 1][16], sum2[STATS ? NO : 1][16];
+    if constexpr (STATS) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum1[o][e] = sum2[o][e] = 0.0f;
+    }
+
     i64 t = wid;
     if (t < ntiles) load_tile(t);
     for (; t < ntiles; t += nwaves) {
@@ -116,6 +128,18 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
             for (int o = 0; o < NO; ++o)
                 acc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[o][s], xv[s], acc[o], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STATS) {
+            // (the rows past the end of the last tile hold copies of its last piece)
+            const float live = (i64)n < rows - t * SL_ROWS ? 1.0f : 0.0f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[o][e] * live;
+                    sum1[o][e] += v;
+                    sum2[o][e] += v * v;
+                }
+        }
         // results to LDS as rows (the lane's row n, 4 adjacent channels per store), then to memory
         // in memory order
 #pragma unroll
@@ -141,6 +165,26 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
             }
         }
     }
+    if constexpr (STATS) {
+        // sums over the 32 rows (lanes) of each half of the wave, in float64, a fixed tree
+        double *out = col_sums + (size_t)wid * 2 * O;
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                double a = (double)sum1[o][e], b = (double)sum2[o][e];
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) {
+                    a += __shfl_xor(a, d, 64);
+                    b += __shfl_xor(b, d, 64);
+                }
+                const int ch = 32 * o + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (n == 0 && ch < O) {
+                    out[ch] = a;
+                    out[O + ch] = b;
+                }
+            }
+    }
 }
 
 }  // namespace mvf
@@ -152,13 +196,14 @@ extern "C" int mvf_linear_rows_supported(int32_t I, int32_t O)
     return I >= 8 && I <= SL_MAX_C && I % 8 == 0 && O >= 4 && O <= SL_MAX_C && O % 4 == 0;
 }
 
-extern "C" int mvf_linear_rows(
+static int linear_rows_launch(
     const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
-    float *y, void *stream)
+    float *y, double *col_sums, int32_t *n_col_sums, void *stream)
 {
     MVF_REQUIRE(mvf_linear_rows_supported(I, O),
                 "linear_rows: I must be a multiple of 8 and O a multiple of 4, both at most 64 (got %d -> %d)", I, O);
     MVF_REQUIRE(rows >= 0, "linear_rows: negative row count");
+    if (n_col_sums) *n_col_sums = 0;
     if (rows == 0) return MVF_OK;
     MVF_REQUIRE(x && weight && y, "linear_rows: null argument");
     MVF_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "linear_rows: x and y must be 16-byte aligned");
@@ -174,12 +219,18 @@ extern "C" int mvf_linear_rows(
     const i64 ntiles = (rows + SL_ROWS - 1) / SL_ROWS;
     i64 nwg = (ntiles + SL_WAVES - 1) / SL_WAVES;
     if (nwg > cus) nwg = cus;
+    if (nwg > SL_MAX_WGS) nwg = SL_MAX_WGS;
+    if (n_col_sums) *n_col_sums = (int32_t)(nwg * SL_WAVES);
     hipStream_t st = (hipStream_t)stream;
     const int kq = I / 8, no = O > 32 ? 2 : 1;
-#define MVF_SL_LAUNCH(KQ_, NO_)                                                                    \
-    hipLaunchKernelGGL((stream_linear_kernel<KQ_, NO_>), dim3((unsigned)nwg), dim3(SL_THREADS), 0, st, \
-                       x, (int)I, weight, bias, (int)O, (i64)rows, y)
-#define MVF_SL_LAUNCH_NO(KQ_) case KQ_: if (no == 1) MVF_SL_LAUNCH(KQ_, 1); else MVF_SL_LAUNCH(KQ_, 2); break
+#define MVF_SL_LAUNCH(KQ_, NO_, ST_)                                                               \
+    hipLaunchKernelGGL((stream_linear_kernel<KQ_, NO_, ST_>), dim3((unsigned)nwg), dim3(SL_THREADS), 0, st, \
+                       x, (int)I, weight, bias, (int)O, (i64)rows, y, col_sums)
+#define MVF_SL_LAUNCH_NO(KQ_)                                                                      \
+    case KQ_:                                                                                      \
+        if (col_sums) { if (no == 1) MVF_SL_LAUNCH(KQ_, 1, true); else MVF_SL_LAUNCH(KQ_, 2, true); } \
+        else { if (no == 1) MVF_SL_LAUNCH(KQ_, 1, false); else MVF_SL_LAUNCH(KQ_, 2, false); }      \
+        break
     switch (kq) {
     MVF_SL_LAUNCH_NO(1); MVF_SL_LAUNCH_NO(2); MVF_SL_LAUNCH_NO(3); MVF_SL_LAUNCH_NO(4);
     MVF_SL_LAUNCH_NO(5); MVF_SL_LAUNCH_NO(6); MVF_SL_LAUNCH_NO(7); default: MVF_SL_LAUNCH_NO(8);
@@ -188,4 +239,25 @@ extern "C" int mvf_linear_rows(
 #undef MVF_SL_LAUNCH
     MVF_LAUNCH_CHECK();
     return MVF_OK;
+}
+
+extern "C" int mvf_linear_rows(
+    const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
+    float *y, void *stream)
+{
+    return linear_rows_launch(x, I, weight, bias, O, rows, y, nullptr, nullptr, stream);
+}
+
+extern "C" size_t mvf_linear_rows_sums_bytes(int32_t O)
+{
+    return O < 1 ? 0 : align_up((size_t)SL_MAX_WGS * SL_WAVES * 2 * (size_t)O * sizeof(double));
+}
+
+extern "C" int mvf_linear_rows_sums(
+    const float *x, int32_t I, const float *weight, const float *bias, int32_t O, int64_t rows,
+    float *y, double *col_sums, size_t col_sums_bytes, int32_t *n_col_sums, void *stream)
+{
+    MVF_REQUIRE(col_sums && n_col_sums && col_sums_bytes >= mvf_linear_rows_sums_bytes(O),
+                "linear_rows_sums: null or too small buffer for the column sums");
+    return linear_rows_launch(x, I, weight, bias, O, rows, y, col_sums, n_col_sums, stream);
 }

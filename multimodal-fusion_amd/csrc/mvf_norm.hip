@@ -431,24 +431,31 @@ extern "C" int mvf_batch_norm_act_forward(
     const float *z, int64_t rows, int32_t C, const float *weight, const float *bias,
     float *running_mean, float *running_var, int32_t training, float momentum, float eps,
     int32_t act, float slope, float *y, float *save_mean, float *save_invstd,
-    void *workspace, size_t workspace_bytes, void *stream)
+    const double *col_sums, int32_t n_col_sums, void *workspace, size_t workspace_bytes, void *stream)
 {
     MVF_REQUIRE(rows >= 1 && C >= 1, "batch_norm_act_forward: rows and C must be positive");
     MVF_REQUIRE(z && y && save_mean && save_invstd, "batch_norm_act_forward: null argument");
     MVF_REQUIRE(training || (running_mean && running_var),
                 "batch_norm_act_forward: running statistics are needed outside train mode");
     MVF_REQUIRE(!training || rows > 1, "batch_norm_act_forward: more than one row per channel is needed in train mode");
-    MVF_REQUIRE(!training || (workspace && workspace_bytes >= mvf_batch_norm_act_workspace_bytes(C)),
+    MVF_REQUIRE(!training || col_sums || (workspace && workspace_bytes >= mvf_batch_norm_act_workspace_bytes(C)),
                 "batch_norm_act_forward: workspace too small");
+    MVF_REQUIRE(!col_sums || n_col_sums >= 1, "batch_norm_act_forward: column sums without partial rows");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)y % 16 == 0;
     const BnGrid g = bn_grid(rows, C, vec ? 4 : 1);
     if (training) {
-        double *partial = (double *)workspace;
-        if (vec) hipLaunchKernelGGL(bn_sums_kernel<4>, g.grid, dim3(BN_THREADS), 0, st, z, (i64)rows, C, g.rows_per_block, partial);
-        else hipLaunchKernelGGL(bn_sums_kernel<1>, g.grid, dim3(BN_THREADS), 0, st, z, (i64)rows, C, g.rows_per_block, partial);
+        const double *partial = col_sums;
+        int nblk = n_col_sums;
+        if (!col_sums) {
+            double *mine = (double *)workspace;
+            if (vec) hipLaunchKernelGGL(bn_sums_kernel<4>, g.grid, dim3(BN_THREADS), 0, st, z, (i64)rows, C, g.rows_per_block, mine);
+            else hipLaunchKernelGGL(bn_sums_kernel<1>, g.grid, dim3(BN_THREADS), 0, st, z, (i64)rows, C, g.rows_per_block, mine);
+            partial = mine;
+            nblk = g.nblk;
+        }
         hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, BN_FOLD_COLS)), dim3(BN_THREADS), 0, st,
-                           (const double *)partial, g.nblk, C, (i64)rows, eps, momentum,
+                           partial, nblk, C, (i64)rows, eps, momentum,
                            running_mean, running_var, save_mean, save_invstd);
     } else {
         hipLaunchKernelGGL(bn_running_terms_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st,

@@ -105,7 +105,7 @@ _SIGNATURES = {
     "mvf_segment_softmax_csr_backward": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P]),
     "mvf_batch_norm_act_workspace_bytes": (_SZ, [_I32]),
     "mvf_batch_norm_act_forward": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _I32, _F, _F, _I32, _F,
-                                             _P, _P, _P, _P, _SZ, _P]),
+                                             _P, _P, _P, _P, _I32, _P, _SZ, _P]),
     "mvf_batch_norm_act_backward": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P, _I32, _I32, _F,
                                               _P, _P, _P, _P, _SZ, _P]),
     "mvf_xty_workspace_bytes": (_SZ, []),
@@ -114,6 +114,8 @@ _SIGNATURES = {
     "mvf_weighted_segment_sum_backward": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _I64, _I64, _P, _P, _P]),
     "mvf_linear_rows_supported": (C.c_int, [_I32, _I32]),
     "mvf_linear_rows": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _P]),
+    "mvf_linear_rows_sums_bytes": (_SZ, [_I32]),
+    "mvf_linear_rows_sums": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _P, _SZ, _P, _P]),
     "mvf_knn": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "mvf_mapping_occlusion": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _I64, _P, _I32, _P]),
     "mvf_gather_csr": (C.c_int, [_P, _I32, _P, _I64, _I64, _P, _P]),

@@ -17,6 +17,7 @@ computation follows modules/multimodal/pooling.py: ``DeepSetFeat.forward``
 :688-699, ``GroupBimodalCSRPool.forward`` :263-315 and
 ``QKVBimodalCSRPool.forward`` :454-547.
 """
+import ctypes
 import math
 
 import torch
@@ -31,7 +32,7 @@ class _BatchNormAct(torch.autograd.Function):
     two backward; only the layer's input is kept for the backward."""
 
     @staticmethod
-    def forward(ctx, z, weight, bias, rm, rv, eps, slope, batch_stats, factor):
+    def forward(ctx, z, weight, bias, rm, rv, eps, slope, batch_stats, factor, col_sums):
         lib = L.load()
         z = z.detach().contiguous()
         rows, C = z.shape
@@ -48,6 +49,7 @@ class _BatchNormAct(torch.autograd.Function):
                 L.ptr(z), rows, C, L.ptr(w), L.ptr(b), L.ptr(rm), L.ptr(rv), int(batch_stats),
                 float(factor), float(eps), int(slope is not None),
                 0.0 if slope is None else float(slope), L.ptr(y), L.ptr(mean), L.ptr(invstd),
+                L.ptr(col_sums), 0 if col_sums is None else col_sums.shape[0],
                 L.ptr(ws), nbytes, L.stream_ptr(dev)))
         ctx.save_for_backward(z, w, b, mean, invstd)
         ctx.slope, ctx.batch_stats = slope, bool(batch_stats)
@@ -71,14 +73,16 @@ class _BatchNormAct(torch.autograd.Function):
                 L.ptr(grad_y), L.ptr(z), rows, C, L.ptr(w), L.ptr(b), L.ptr(mean), L.ptr(invstd),
                 int(ctx.batch_stats), int(slope is not None), 0.0 if slope is None else float(slope),
                 L.ptr(gz), L.ptr(gw), L.ptr(gb), L.ptr(ws), nbytes, L.stream_ptr(dev)))
-        return gz, gw, gb, None, None, None, None, None, None
+        return gz, gw, gb, None, None, None, None, None, None, None
 
 
-def batch_norm_act(z, bn, act):
+def batch_norm_act(z, bn, act, col_sums=None):
     """``act(bn(z))`` for an ``nn.BatchNorm1d`` (train or eval mode, running
     statistics and ``num_batches_tracked`` updated as the module does) followed
     by a LeakyReLU, on this package's kernels when z is a float32 [rows, C]
-    tensor on the HIP device; other inputs and activations take the modules."""
+    tensor on the HIP device; other inputs and activations take the modules.
+    col_sums: partial column sums of z and z * z as ``linear(..., want_sums=True)``
+    returns them (batch statistics without another pass over z)."""
     fused_act = isinstance(act, torch.nn.LeakyReLU)
     if not (z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and z.shape[0] > 0
             and isinstance(bn, torch.nn.BatchNorm1d)
@@ -100,7 +104,8 @@ def batch_norm_act(z, bn, act):
     y = _BatchNormAct.apply(z, bn.weight, bn.bias,
                             bn.running_mean if use_running else None,
                             bn.running_var if use_running else None, bn.eps,
-                            float(act.negative_slope) if fused_act else None, batch_stats, factor)
+                            float(act.negative_slope) if fused_act else None, batch_stats, factor,
+                            col_sums if batch_stats else None)
     return y if fused_act else act(y)
 
 
@@ -137,14 +142,15 @@ class _Weights:
         self.out_features, self.in_features = weight.shape
 
 
-def _product(x, weight, bias):
-    """x W^T + b over many rows: the streaming float32 MFMA kernel (mvf_linear_rows)
-    for at most 64 input and output columns, one launch of the layer-chain
-    kernel with a single plain layer for wider ones (both stream the rows at
-    a higher rate than the library GEMM does for these shapes), the library
-    GEMM otherwise."""
+def _product(x, weight, bias, want_sums=False):
+    """(x W^T + b, partial column sums or None) over many rows: the streaming
+    float32 MFMA kernel (mvf_linear_rows, which can leave the column sums of its
+    output for BatchNorm's batch statistics) for at most 64 input and output
+    columns, one launch of the layer-chain kernel with a single plain layer for
+    wider ones (both stream the rows at a higher rate than the library GEMM
+    does for these shapes), the library GEMM otherwise."""
     if max(weight.shape) > 256 or x.shape[0] < 4096:
-        return torch.nn.functional.linear(x, weight, bias)
+        return torch.nn.functional.linear(x, weight, bias), None
     dense = P._dense
     w = weight.detach()
     specs, xp = dense.aligned_input(
@@ -152,13 +158,21 @@ def _product(x, weight, bias):
     lib = L.load()
     cout, cin = specs[0].cout, specs[0].cin
     if not (lib.mvf_linear_rows_supported(cin, cout) and xp.is_contiguous() and xp.data_ptr() % 16 == 0):
-        return dense.run_layers(specs, xp)
+        return dense.run_layers(specs, xp), None
     wp, bp = specs[0].weight.float().contiguous(), None if bias is None else bias.detach().float().contiguous()
-    y = torch.empty((xp.shape[0], cout), dtype=torch.float32, device=xp.device)
-    with torch.cuda.device(xp.device):
-        L.check(lib.mvf_linear_rows(L.ptr(xp), cin, L.ptr(wp), L.ptr(bp), cout, xp.shape[0], L.ptr(y),
-                                    L.stream_ptr(xp.device)))
-    return y
+    dev = xp.device
+    y = torch.empty((xp.shape[0], cout), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if not want_sums:
+            L.check(lib.mvf_linear_rows(L.ptr(xp), cin, L.ptr(wp), L.ptr(bp), cout, xp.shape[0], L.ptr(y),
+                                        L.stream_ptr(dev)))
+            return y, None
+        nbytes = lib.mvf_linear_rows_sums_bytes(cout)
+        sums = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+        n = ctypes.c_int32(0)
+        L.check(lib.mvf_linear_rows_sums(L.ptr(xp), cin, L.ptr(wp), L.ptr(bp), cout, xp.shape[0], L.ptr(y),
+                                         L.ptr(sums), nbytes, ctypes.byref(n), L.stream_ptr(dev)))
+    return y, sums[:n.value * 2 * cout].view(n.value, 2, cout)
 
 
 class _Linear(torch.autograd.Function):
@@ -168,37 +182,49 @@ class _Linear(torch.autograd.Function):
     of the memory bandwidth."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, want_sums):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return _product(x, weight, bias)
+        y, sums = _product(x, weight, bias, want_sums)
+        if sums is None:
+            sums = torch.empty(0, dtype=torch.float64, device=x.device)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, _grad_sums):
         x, weight = ctx.saved_tensors
         grad_y = grad_y.contiguous()
-        gx = _product(grad_y, weight.t(), None) if ctx.needs_input_grad[0] else None
+        gx = _product(grad_y, weight.t(), None)[0] if ctx.needs_input_grad[0] else None
         gw = xty(grad_y, x) if ctx.needs_input_grad[1] else None
         gb = xty(grad_y).view(-1) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def linear(lin, x):
+def linear(lin, x, want_sums=False):
     """``lin(x)`` for an ``nn.Linear`` on float32 [rows, C] device tensors,
     with the weight gradient on this package's kernel; anything else takes the
-    module."""
+    module.  want_sums: returns (output, partial column sums of the output and
+    its square or None) for ``batch_norm_act``."""
     if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
             and lin.weight.is_cuda and lin.weight.dtype == torch.float32):
-        return _Linear.apply(x, lin.weight, lin.bias)
-    return lin(x)
+        y, sums = _Linear.apply(x, lin.weight, lin.bias, bool(want_sums))
+        return (y, sums if sums.numel() else None) if want_sums else y
+    return (lin(x), None) if want_sums else lin(x)
 
 
 def mlp(seq, x):
-    """MLP of base_modules.py:38-48: per block Linear (library GEMMs, weight
-    gradient by mvf_xty), then BatchNorm1d and the activation in one pair of
-    kernels."""
+    """MLP of base_modules.py:38-48: per block Linear (streaming MFMA products,
+    weight gradient by mvf_xty), then BatchNorm1d and the activation in one pair
+    of kernels; in train mode the Linear leaves the column sums the batch
+    statistics are made of."""
     for block in seq:
-        x = batch_norm_act(linear(block[0], x), block[1].batch_norm, block[2])
+        bn = block[1].batch_norm
+        if bn.training or bn.running_mean is None:
+            z, sums = linear(block[0], x, want_sums=True)
+        else:
+            z, sums = linear(block[0], x), None
+        x = batch_norm_act(z, bn, block[2], col_sums=sums)
     return x
 
 

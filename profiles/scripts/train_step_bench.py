@@ -20,7 +20,8 @@ x_map = torch.rand(Vw, 8, device=dev, requires_grad=True)
 torch.manual_seed(0)
 mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=64, out_mod=64).to(dev).train()
 own = (training.batch_norm_act, training.linear)
-plain = (lambda z, bn, act: act(bn(z)), lambda lin, x: lin(x))
+plain = (lambda z, bn, act, col_sums=None: act(bn(z)),
+         lambda lin, x, want_sums=False: (lin(x), None) if want_sums else lin(x))
 
 
 def step():

@@ -354,3 +354,34 @@ def test_linear_rows_streaming_kernel(rows, cin, cout, bias):
     mag = x.double().abs() @ w.double().abs().T + 1e-30
     assert float(((y[:rows].double() - want).abs() / mag).max()) < 1e-6
     assert float((y[rows] - 7.0).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(100003, 64, 64), (5003, 8, 32), (4099, 40, 36), (65, 16, 4)])
+def test_linear_rows_column_sums_feed_batch_norm(rows, cin, cout):
+    """The Linear's streaming pass leaves the column sums of its output (mvf_linear_rows_sums); the
+    BatchNorm forward that folds its batch statistics from them equals the one that reads the rows,
+    and both equal float64 (the MLP block of the differentiable path, training.mlp)."""
+    from mvfusion import training, pooling
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, cin, device="cuda") + 0.3).requires_grad_(True)
+    seq = pooling.MLP([cin, cout], bias=False).cuda().train()
+    with torch.no_grad():
+        seq[0][1].batch_norm.weight.uniform_(0.5, 1.5)
+        seq[0][1].batch_norm.bias.uniform_(-0.3, 0.3)
+    lin, bn = seq[0][0], seq[0][1].batch_norm
+    z, sums = training.linear(lin, x, want_sums=True)
+    if rows >= 4096:
+        assert sums is not None and sums.shape[1:] == (2, cout)
+        want = torch.stack([z.detach().double().sum(0), (z.detach().double() ** 2).sum(0)])
+        got = sums.sum(0)
+        assert float(((got - want).abs() / want.abs().clamp_min(1e-30)).max()) < 1e-6
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+    y_fused = training.mlp(seq, x)
+    y_fused.sum().backward()
+    assert x.grad is not None and lin.weight.grad is not None and bool(torch.isfinite(x.grad).all())
+    after = {k: v.clone() for k, v in bn.state_dict().items()}
+    bn.load_state_dict(state)
+    y_plain = training.batch_norm_act(training.linear(lin, x), bn, seq[0][2])
+    assert close(y_fused.detach().cpu().numpy(), y_plain.detach().cpu().numpy(), 2e-6)
+    for k in ("running_mean", "running_var"):
+        assert close(after[k].cpu().numpy(), bn.state_dict()[k].cpu().numpy(), 1e-6)
