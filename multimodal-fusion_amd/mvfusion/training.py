@@ -6,10 +6,12 @@ attention kernels (``dense.py``), which implement BatchNorm with running
 statistics and record no graph.  In ``.train()``, and in ``.eval()`` whenever an
 input or a parameter requires a gradient, the pools are composed here from
 differentiable pieces instead (BatchNorm follows the module's mode): the Linear
-of a dense layer is a library GEMM (torch) for its output and input gradient
-and this package's ``mvf_xty`` for its weight gradient (``linear``), its
+of a dense layer is this package's streaming MFMA product for its output and
+input gradient (``mvf_linear_rows``; a library GEMM for shapes it does not
+take) and ``mvf_xty`` for its weight and bias gradients (``linear``), its
 BatchNorm1d + LeakyReLU tail one pair of this package's kernels forward and
-one backward (``batch_norm_act``), and the CSR operations are this package's
+one backward (``batch_norm_act``), the attention-weighted sum one kernel each
+way (``weighted_segment_sum``), and the CSR operations are this package's
 kernels, all wrapped in ``torch.autograd.Function``
 (``pooling.segment_csr`` / ``gather_csr`` / ``segment_softmax_csr``).  The
 computation follows modules/multimodal/pooling.py: ``DeepSetFeat.forward``
