@@ -433,8 +433,14 @@ def expand_group_feat(A, num_groups, num_channels):
     if num_groups == 1:
         A = A.view(-1, 1)
     elif num_groups < num_channels:
-        sizes = group_sizes(num_channels, num_groups).to(A.device)
-        A = A.repeat_interleave(sizes, dim=1)
+        if num_channels % num_groups == 0 and A.dim() == 2:
+            # equal groups: the same values as repeat_interleave, as a broadcast (its gradient
+            # is a plain sum over the group's channels instead of an index_add)
+            A = A.unsqueeze(2).expand(-1, num_groups, num_channels // num_groups).reshape(
+                A.shape[0], num_channels)
+        else:
+            sizes = group_sizes(num_channels, num_groups).to(A.device)
+            A = A.repeat_interleave(sizes, dim=1)
     return A
 
 

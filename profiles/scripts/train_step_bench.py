@@ -18,7 +18,11 @@ x_main = torch.rand(N, 32, device=dev, requires_grad=True)
 x_mod = torch.rand(Vw, 64, device=dev, requires_grad=True)
 x_map = torch.rand(Vw, 8, device=dev, requires_grad=True)
 torch.manual_seed(0)
-mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=64, out_mod=64).to(dev).train()
+# argument "group": GroupBimodalCSRPool with 4 groups (the flagship model's setting) instead
+if len(sys.argv) > 1 and sys.argv[1] == "group":
+    mod = pooling.GroupBimodalCSRPool(in_map=8, in_mod=64, num_groups=4, gating=True).to(dev).train()
+else:
+    mod = pooling.QKVBimodalCSRPool(in_main=32, in_map=8, in_mod=64, out_mod=64).to(dev).train()
 own = (training.batch_norm_act, training.linear)
 plain = (lambda z, bn, act, col_sums=None: act(bn(z)),
          lambda lin, x, want_sums=False: (lin(x), None) if want_sums else lin(x))
@@ -27,7 +31,7 @@ plain = (lambda z, bn, act, col_sums=None: act(bn(z)),
 def step():
     mod.zero_grad(set_to_none=True)
     x_main.grad = x_mod.grad = x_map.grad = None
-    out = mod(x_main, x_mod, x_map, ptr)
+    out = mod(x_main if isinstance(mod, pooling.QKVBimodalCSRPool) else None, x_mod, x_map, ptr)
     out.sum().backward()
 
 
