@@ -318,6 +318,72 @@ def weighted_segment_sum(x, att, ptr, num_groups):
     return _WeightedSegmentSum.apply(x, att, ptr, num_groups)
 
 
+def _group_shape_ok(C, num_groups):
+    cv = C // 4
+    return (C % 4 == 0 and C % num_groups == 0 and (C // num_groups) % 4 == 0 and 1 <= cv <= 64
+            and cv & (cv - 1) == 0 and (cv // num_groups) & (cv // num_groups - 1) == 0)
+
+
+class _SegmentDot(torch.autograd.Function):
+    """comp[r, g] = sum over the channels c of group g of keys[r, c] * queries[segment of r, c]:
+    the compatibilities of the views with the query of their point
+    (pooling.py:497-512: ``(K * gather_csr(Q)).view(-1, G, D).sum(2)``) without the
+    gathered queries or the products in memory.  Forward and both gradients are the
+    kernels of the attention-weighted sum with the roles of the tensors exchanged."""
+
+    @staticmethod
+    def forward(ctx, keys, queries, ptr, num_groups):
+        lib = L.load()
+        keys, queries = keys.detach().contiguous(), queries.detach().contiguous()
+        dev = keys.device
+        rows, C = keys.shape
+        nseg = ptr.shape[0] - 1
+        row2seg = P._dense.csr_row_segments(ptr, rows, outside=-1)
+        comp = torch.empty((rows, num_groups), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            # (the weights argument is only read for the row gradient, which is not asked for)
+            L.check(lib.mvf_weighted_segment_sum_backward(
+                L.ptr(queries), L.ptr(keys), L.ptr(keys), C, num_groups, L.ptr(row2seg), rows, nseg,
+                None, L.ptr(comp), L.stream_ptr(dev)))
+        ctx.save_for_backward(keys, queries, ptr, row2seg)
+        ctx.num_groups = num_groups
+        return comp
+
+    @staticmethod
+    def backward(ctx, grad_comp):
+        lib = L.load()
+        keys, queries, ptr, row2seg = ctx.saved_tensors
+        dev = keys.device
+        rows, C = keys.shape
+        nseg = ptr.shape[0] - 1
+        grad_comp = grad_comp.contiguous()
+        gk = gq = None
+        with torch.cuda.device(dev):
+            if ctx.needs_input_grad[0]:
+                gk = torch.empty_like(keys)
+                L.check(lib.mvf_weighted_segment_sum_backward(
+                    L.ptr(queries), L.ptr(keys), L.ptr(grad_comp), C, ctx.num_groups, L.ptr(row2seg),
+                    rows, nseg, L.ptr(gk), None, L.stream_ptr(dev)))
+            if ctx.needs_input_grad[1]:
+                gq = torch.empty_like(queries)
+                L.check(lib.mvf_weighted_segment_sum(L.ptr(keys), L.ptr(grad_comp), C, ctx.num_groups,
+                                                     L.ptr(ptr), nseg, L.ptr(gq), L.stream_ptr(dev)))
+        return gk, gq, None, None
+
+
+def segment_dot(keys, queries, ptr, num_groups):
+    """[rows, G] group-wise dot products of every key row with the query row of its segment
+    (queries: one row per segment); the composition with ``gather_csr`` for shapes the
+    kernels do not take."""
+    C = keys.shape[1]
+    if (keys.is_cuda and keys.dtype == torch.float32 and queries.dtype == torch.float32
+            and keys.dim() == 2 and keys.shape[0] > 0 and queries.shape == (ptr.shape[0] - 1, C)
+            and ptr.dtype == torch.int64 and _group_shape_ok(C, num_groups)):
+        return _SegmentDot.apply(keys, queries, ptr, num_groups)
+    q = P.gather_csr(queries, ptr)
+    return (keys.view(-1, num_groups, C // num_groups) * q.view(-1, num_groups, C // num_groups)).sum(dim=2)
+
+
 def attend(m, x_mod, comp, ptr):
     """Softmax of the compatibilities over the views of a point, attention-
     weighted sum of the values, optional gate from the best compatibility."""
@@ -347,12 +413,19 @@ def qkv_pool(m, x_main, x_mod, x_map, ptr):
         keys = linear(m.K, mlp(m.E_mix_K, torch.cat([x_map, x_mod], dim=1)))
     else:
         keys = linear(m.K, x_map)
-    if m.use_mod_q:
-        queries = linear(m.Q, mlp(m.E_mix_Q, torch.cat([P.gather_csr(x_main, ptr), x_mod], dim=1)))
+    if not m.use_mod_q and not m.save_last:
+        # the queries stay one row per point: every view meets the row of its point in the kernel
+        queries = linear(m.Q, x_main)
+        if m.dim_scaling:
+            queries = queries / math.sqrt(m.nc_qk)
+        comp = segment_dot(keys, queries, ptr, m.num_groups)
     else:
-        queries = P.gather_csr(linear(m.Q, x_main), ptr)
-    comp = (keys.view(-1, m.num_groups, m.nc_qk) * queries.view(-1, m.num_groups, m.nc_qk)).sum(dim=2)
-    if m.dim_scaling:
-        comp = comp / math.sqrt(m.nc_qk)
+        if m.use_mod_q:
+            queries = linear(m.Q, mlp(m.E_mix_Q, torch.cat([P.gather_csr(x_main, ptr), x_mod], dim=1)))
+        else:
+            queries = P.gather_csr(linear(m.Q, x_main), ptr)
+        comp = (keys.view(-1, m.num_groups, m.nc_qk) * queries.view(-1, m.num_groups, m.nc_qk)).sum(dim=2)
+        if m.dim_scaling:
+            comp = comp / math.sqrt(m.nc_qk)
     x_pool, att, gate = attend(m, x_mod, comp, ptr)
     return x_pool, dict(x_map=x_map, x_mod=x_mod, K=keys, Q=queries, C=comp, A=att, G=gate)

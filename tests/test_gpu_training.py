@@ -385,3 +385,29 @@ def test_linear_rows_column_sums_feed_batch_norm(rows, cin, cout):
     assert close(y_fused.detach().cpu().numpy(), y_plain.detach().cpu().numpy(), 2e-6)
     for k in ("running_mean", "running_var"):
         assert close(after[k].cpu().numpy(), bn.state_dict()[k].cpu().numpy(), 1e-6)
+
+
+@pytest.mark.parametrize("D,G", [(16, 1), (8, 4), (8, 1), (4, 8), (6, 2)])
+def test_segment_dot_and_its_gradients(D, G):
+    """training.segment_dot (a view's key against the query of its point, per group) against the
+    composition gather_csr + product + sum in float64: values and both gradients; a shape the
+    kernels do not take (6 channels per group) runs the composition."""
+    from mvfusion import training
+    rng = np.random.default_rng(D * 10 + G)
+    counts = np.minimum(rng.poisson(3, 2500), 15)
+    counts[3] = 200
+    ptr = T(np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)).cuda()
+    rows, C = int(counts.sum()), D * G
+    keys = torch.randn(rows, C, device="cuda").requires_grad_(True)
+    q = torch.randn(len(counts), C, device="cuda").requires_grad_(True)
+    wgt = torch.randn(rows, G, device="cuda")
+    comp = training.segment_dot(keys, q, ptr, G)
+    (comp * wgt).sum().backward()
+    kd, qd = keys.detach().double().requires_grad_(True), q.detach().double().requires_grad_(True)
+    seg = torch.repeat_interleave(torch.arange(len(counts), device="cuda"), T(counts).cuda())
+    ref = (kd.view(-1, G, D) * qd[seg].view(-1, G, D)).sum(2)
+    (ref * wgt.double()).sum().backward()
+    assert comp.shape == (rows, G)
+    assert close(comp.detach().cpu().numpy(), ref.detach().cpu().numpy(), 2e-6)
+    assert close(keys.grad.cpu().numpy(), kd.grad.cpu().numpy(), 2e-6)
+    assert close(q.grad.cpu().numpy(), qd.grad.cpu().numpy(), 2e-6)
