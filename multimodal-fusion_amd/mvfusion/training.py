@@ -230,13 +230,30 @@ def mlp(seq, x):
     return x
 
 
+def mlp_on_rows_and_sets(seq, x, x_set, ptr):
+    """``mlp(seq, cat((x, gather_csr(x_set, ptr)), 1))`` without the concatenated rows: the
+    first Linear is split by columns, [x | x_set[seg]] W^T = x Wa^T + (x_set Wb^T + b)[seg],
+    so the set features go through their half once per segment instead of once per row
+    (DeepSetFeat's 'concatenation' fusion, pooling.py:669-681)."""
+    lin, bn, act = seq[0][0], seq[0][1].batch_norm, seq[0][2]
+    d = x.shape[1]
+    za = _Linear.apply(x, lin.weight[:, :d], None, False)[0]
+    zb = _Linear.apply(x_set, lin.weight[:, d:], lin.bias, False)[0]
+    z = za + P.gather_csr(zb, ptr)
+    y = batch_norm_act(z, bn, act)
+    return mlp(seq[1:], y) if len(seq) > 1 else y
+
+
 def deep_set_feat(m, x, ptr):
     x = mlp(m.mlp_elt_1, x)
     sets = [P.segment_csr(x, ptr, reduce=p) for p in m.pool]
     if m.use_num:
         sets.append(P._set_num(ptr).view(-1, 1))
     x_set = torch.cat(sets, dim=-1) if len(sets) > 1 else sets[0]
-    x_set = P.gather_csr(mlp(m.mlp_set, x_set), ptr)
+    x_set = mlp(m.mlp_set, x_set)
+    if m.fusion == 'concatenation' and x.is_cuda and x.dtype == torch.float32:
+        return mlp_on_rows_and_sets(m.mlp_elt_2, x, x_set, ptr)
+    x_set = P.gather_csr(x_set, ptr)
     if m.fusion == 'residual':
         x_out = x + x_set
     elif m.fusion == 'concatenation':
