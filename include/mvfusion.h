@@ -716,6 +716,21 @@ int mvf_mapping_occlusion(
     const int64_t *images, int64_t rows, const uint8_t *seen, int64_t n_images, float *out,
     int32_t out_stride, void *stream);
 
+/* ---------------------------------------------------------------------- *
+ * Local point order of MapImages (host code, no device work).
+ * The reference's radius samplers (core/data_transform/transforms.py:326,332,
+ * 380,386) return the points of a sample in the order of an sklearn
+ * KDTree(leaf_size=50).idx_array; depth ties and shared centre pixels are
+ * resolved on that order (core/multimodal/visibility.py:1157,1183-1187).
+ * mvf_kdtree_order rebuilds that index array: h_pos [n] HOST rows of `stride`
+ * floats whose first dims (2: cylinder sampling, 3: sphere sampling) columns
+ * are the coordinates (numbers, no NaN), h_order [n] HOST int64.  threads < 1:
+ * as many as the host offers (at most 16).  Same permutation as sklearn for
+ * any thread count.
+ * ---------------------------------------------------------------------- */
+int mvf_kdtree_order(const float *h_pos, int64_t n, int32_t dims, int64_t stride, int64_t leaf_size,
+                     int64_t *h_order, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

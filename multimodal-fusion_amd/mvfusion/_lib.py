@@ -116,6 +116,7 @@ _SIGNATURES = {
     "mvf_linear_rows": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _P]),
     "mvf_linear_rows_sums_bytes": (_SZ, [_I32]),
     "mvf_linear_rows_sums": (C.c_int, [_P, _I32, _P, _P, _I32, _I64, _P, _P, _SZ, _P, _P]),
+    "mvf_kdtree_order": (C.c_int, [_P, _I64, _I32, _I64, _I64, _P, _I32]),
     "mvf_knn": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _P]),
     "mvf_mapping_occlusion": (C.c_int, [_P, _I32, _I32, _P, _P, _I64, _P, _I64, _P, _I32, _P]),
     "mvf_gather_csr": (C.c_int, [_P, _I32, _P, _I64, _I64, _P, _P]),

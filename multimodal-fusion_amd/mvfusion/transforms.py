@@ -77,14 +77,44 @@ _NO_MAPPING_MSG = (
     "transformation.")
 
 
-def kdtree_order(pos, cylinder):
+def kdtree_order(pos, cylinder, threads=0):
     """Traversal order of the KD-tree the reference's radius samplers build
     (transforms.py:326,380): ``query_radius`` returns the points of that order
-    that fall inside the radius."""
-    from sklearn.neighbors import KDTree
-    p = np.asarray(pos.detach().cpu())
-    tree = KDTree(p[:, :2] if cylinder else p, leaf_size=50)
-    return torch.from_numpy(np.asarray(tree.idx_array).astype(np.int64))
+    that fall inside the radius.  Computed by the library's own host routine
+    (``mvf_kdtree_order``: the same permutation as
+    ``sklearn.neighbors.KDTree(leaf_size=50).idx_array``, without sklearn)."""
+    p = pos.detach()
+    if p.is_cuda:
+        p = p.cpu()
+    p = np.ascontiguousarray(np.asarray(p, dtype=np.float32))
+    n = p.shape[0]
+    order = np.empty(n, dtype=np.int64)
+    if n:
+        L.check(L.load().mvf_kdtree_order(
+            p.ctypes.data, n, 2 if cylinder else 3, p.shape[1], 50, order.ctypes.data, int(threads)))
+    return torch.from_numpy(order)
+
+
+def _source_key(tag, tensors):
+    """What a staging cache remembers of its sources: the tensor objects
+    themselves (so that their storage cannot be freed and handed to another
+    tensor behind the cache's back) with the version counter they had."""
+    return tag, [(t, t._version) if torch.is_tensor(t) else t for t in tensors]
+
+
+def _same_sources(key, tag, tensors):
+    """True when `tensors` are the very objects `key` was taken from, unmodified
+    since (in-place writes bump the version counter; a replaced attribute is
+    another object)."""
+    if key[0] != tag or len(key[1]) != len(tensors):
+        return False
+    for old, new in zip(key[1], tensors):
+        if torch.is_tensor(new):
+            if not (isinstance(old, tuple) and old[0] is new and old[1] == new._version):
+                return False
+        elif isinstance(old, tuple) or old != new:
+            return False
+    return True
 
 
 _VIEW_DTYPE = np.dtype({
@@ -444,7 +474,7 @@ class MapImages(ImageTransform):
         ``data`` for the next call, as the reference keeps the tree itself
         (transforms.py:325-329,379-383)."""
         order = getattr(data, ORDER_KEY, None)
-        if order is not None:
+        if order is not None and order.shape[0] == data.pos.shape[0]:
             return order
         if self.point_order == 'index':
             return None
@@ -672,10 +702,8 @@ class MapImages(ImageTransform):
         ids = getattr(data, self.key)
         names = ('linearity', 'planarity', 'scattering', 'norm')
         src = [data.pos, ids, order] + [getattr(data, k, None) for k in names]
-        key = (str(device),) + tuple(
-            None if t is None else (t.data_ptr(), t._version, tuple(t.shape)) for t in src)
         cached = getattr(data, '_mvf_staged', None)
-        if cached is not None and cached[0] == key:
+        if cached is not None and _same_sources(cached[0], str(device), src):
             return cached[1]
         if not ids.is_cuda:
             # host ids: range and distinctness are settled here, without a device round trip
@@ -714,7 +742,7 @@ class MapImages(ImageTransform):
         staged = (pos.contiguous(), ids.contiguous(), inv,
                   [a.contiguous() if a is not None else None for a in attrs], num_points)
         try:
-            data._mvf_staged = (key, staged)
+            data._mvf_staged = (_source_key(str(device), src), staged)
         except Exception:
             pass
         return staged
@@ -726,14 +754,13 @@ class MapImages(ImageTransform):
         src = [images.pos, images.extrinsic, images.crop_offsets] + [
             getattr(images, k, None) for k in ('fx', 'fy', 'mx', 'my', 'opk', 'xi', 'k1', 'k2',
                                                 'gamma1', 'gamma2', 'u0', 'v0')]
-        key = (str(device), camera) + tuple(
-            (t.data_ptr(), t._version, tuple(t.shape)) if torch.is_tensor(t) else repr(t) for t in src)
+        tag = (str(device), camera)
         cached = getattr(images, '_mvf_views', None)
-        if cached is not None and cached[0] == key:
+        if cached is not None and _same_sources(cached[0], tag, src):
             return cached[1]
         views = pack_views(images, camera).to(device)
         try:
-            images._mvf_views = (key, views)
+            images._mvf_views = (_source_key(tag, src), views)
         except Exception:
             pass
         return views
