@@ -291,7 +291,9 @@ int mvf_map_images_splat(
  * that last used `workspace` issued, from the tile bins it left there.  Pass
  * the same sizes as to that call.  d_out (device, caller zeroes it):
  * [0] += LDS atomic-minimum wave-instructions, [1] += lane-level atomics
- * (pixels + cells written), [2] += (splat, tile) entries. */
+ * (pixels + cells written), [2] += (splat, tile) entries, [3] += in-view
+ * (point, view) pairs (the records the binning pass staged); d_out holds 4
+ * 64-bit words. */
 int mvf_profile_zbuffer_ops(
     void *workspace, size_t workspace_bytes, int64_t n, int32_t V,
     const mvf_vis_params *h_params, int64_t num_points, int64_t pair_capacity,

@@ -38,11 +38,18 @@
 //   twice as fast and leaves exactly the same arrangement.
 //
 // The two children of a node are independent: the upper levels of the
-// recursion hand their left child to another thread.
+// recursion hand their left child to a pool of worker threads that the library
+// keeps for the life of the process (creating threads costs more than the build
+// itself once the process has mapped a GPU).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -76,8 +83,15 @@ template <int D, int DIM> struct Less {
     bool operator()(const Rec<D> &a, const Rec<D> &b) const { return key_of<D, DIM>(a) < key_of<D, DIM>(b); }
 };
 
-// Scratch of one thread: flags and position lists of the partition.
-struct Scratch { std::vector<uint8_t> flag; std::vector<uint32_t> left, right; };
+// Scratch of one thread: flags and position lists of the partition.  Every thread keeps
+// its own for the life of the process: in a process that has mapped a GPU, returning
+// large blocks to the system and faulting them in again costs more than the build.
+struct Scratch { std::vector<uint8_t> flag; std::vector<uint32_t> left, right; std::vector<uint32_t> recs; };
+static Scratch &thread_scratch()
+{
+    static thread_local Scratch s;
+    return s;
+}
 
 constexpr int64_t PARTITION_BRANCHLESS_MIN = 96;
 
@@ -177,8 +191,76 @@ int split_dim(const Rec<D> *r, int64_t n)
     return best;
 }
 
+// Worker threads shared by all calls.  A job is a group of tasks; the caller of
+// run_group works on tasks itself while it waits for its group.
+class Pool {
+public:
+    struct Group { std::atomic<int> pending{0}; };
+    static Pool &get()
+    {
+        static Pool *p = new Pool();          // never destroyed: workers may outlive static teardown
+        return *p;
+    }
+    int size() const { return (int)workers_.size(); }
+    void submit(Group &g, std::function<void()> fn)
+    {
+        g.pending.fetch_add(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> lock(m_);
+            tasks_.emplace_back(Task{&g, std::move(fn)});
+        }
+        cv_.notify_one();
+    }
+    // Runs queued tasks (of any group) until group g has none left.
+    void wait(Group &g)
+    {
+        while (g.pending.load(std::memory_order_acquire) > 0) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                if (tasks_.empty()) { lock.unlock(); std::this_thread::yield(); continue; }
+                t = std::move(tasks_.front());
+                tasks_.pop_front();
+            }
+            t.fn();
+            t.group->pending.fetch_sub(1, std::memory_order_release);
+        }
+    }
+
+private:
+    struct Task { Group *group; std::function<void()> fn; };
+    Pool()
+    {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = hw ? (int)(hw < 16 ? hw : 16) : 4;
+        for (int i = 0; i < n - 1; ++i) {
+            workers_.emplace_back([this] { loop(); });
+            workers_.back().detach();
+        }
+    }
+    void loop()
+    {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> lock(m_);
+                cv_.wait(lock, [this] { return !tasks_.empty(); });
+                t = std::move(tasks_.front());
+                tasks_.pop_front();
+            }
+            t.fn();
+            t.group->pending.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> tasks_;
+    std::vector<std::thread> workers_;
+};
+
 template <int D>
-void build(Rec<D> *r, int64_t node, int64_t n_nodes, int64_t n, int spawn_levels, Scratch *S)
+void build(Rec<D> *r, int64_t node, int64_t n_nodes, int64_t n, int spawn_levels, Scratch *S,
+           Pool::Group *group)
 {
     if (2 * node + 1 >= n_nodes || n < 2) return;
     const int64_t mid = n / 2;
@@ -188,39 +270,47 @@ void build(Rec<D> *r, int64_t node, int64_t n_nodes, int64_t n, int spawn_levels
     default: select_nth<D, (D > 2 ? 2 : 0)>(r, r + mid, r + n, *S); break;
     }
     if (spawn_levels > 0) {
-        std::thread left([=] { Scratch own; build<D>(r, 2 * node + 1, n_nodes, mid, spawn_levels - 1, &own); });
-        build<D>(r + mid, 2 * node + 2, n_nodes, n - mid, spawn_levels - 1, S);
-        left.join();
+        Pool::get().submit(*group, [=] {
+            build<D>(r, 2 * node + 1, n_nodes, mid, spawn_levels - 1, &thread_scratch(), group);
+        });
+        build<D>(r + mid, 2 * node + 2, n_nodes, n - mid, spawn_levels - 1, S, group);
     } else {
-        build<D>(r, 2 * node + 1, n_nodes, mid, 0, S);
-        build<D>(r + mid, 2 * node + 2, n_nodes, n - mid, 0, S);
+        build<D>(r, 2 * node + 1, n_nodes, mid, 0, S, group);
+        build<D>(r + mid, 2 * node + 2, n_nodes, n - mid, 0, S, group);
     }
 }
 
 template <int D>
 void order_of(const float *pos, int64_t n, int64_t stride, int64_t leaf_size, int64_t *out, int threads)
 {
-    std::vector<Rec<D>> recs((size_t)n);
+    Scratch &S = thread_scratch();
+    if (S.recs.size() < (size_t)n * (D + 1)) S.recs.resize((size_t)n * (D + 1));
+    Rec<D> *recs = reinterpret_cast<Rec<D> *>(S.recs.data());
+    static_assert(sizeof(Rec<D>) == 4 * (D + 1), "records are packed 32-bit words");
     for (int64_t i = 0; i < n; ++i) {
-        for (int j = 0; j < D; ++j) recs[(size_t)i].k[j] = float_key(pos[i * stride + j]);
-        recs[(size_t)i].idx = (uint32_t)i;
+        for (int j = 0; j < D; ++j) recs[i].k[j] = float_key(pos[i * stride + j]);
+        recs[i].idx = (uint32_t)i;
     }
     const double ratio = (double)(n - 1) / (double)leaf_size;
     const int64_t n_levels = (int64_t)(std::log2(ratio > 1.0 ? ratio : 1.0) + 1.0);
     const int64_t n_nodes = ((int64_t)1 << n_levels) - 1;
+    // subtrees handed to the pool: about four per thread, so that uneven ones even out
     int spawn = 0;
-    while ((1 << spawn) < threads && spawn < 6) ++spawn;
-    if (n < 20000) spawn = 0;                       // not worth a thread
-    Scratch S;
-    build<D>(recs.data(), 0, n_nodes, n, spawn, &S);
-    for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)recs[(size_t)i].idx;
+    if (threads > 1 && n >= 20000) {
+        while ((1 << spawn) < 4 * threads && spawn < 8) ++spawn;
+    }
+    Pool::Group group;
+    build<D>(recs, 0, n_nodes, n, spawn, &S, &group);
+    if (spawn > 0) Pool::get().wait(group);
+    for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)recs[i].idx;
 }
 
 }  // namespace
 
 // h_pos: [n] rows of `stride` floats (host); the first `dims` (2 or 3) columns
 // are the tree's coordinates (numbers, no NaN).  h_order: [n] int64, the tree's
-// index array.  threads < 1: as many as the host offers, at most 16.
+// index array.  threads: 1 = the calling thread alone; anything else shares the
+// work with the library's worker threads (as many as the host offers, at most 15).
 extern "C" int mvf_kdtree_order(
     const float *h_pos, int64_t n, int32_t dims, int64_t stride, int64_t leaf_size,
     int64_t *h_order, int32_t threads)
@@ -231,10 +321,7 @@ extern "C" int mvf_kdtree_order(
                        (long long)n, dims, (long long)stride, (long long)leaf_size);
         return MVF_E_INVALID;
     }
-    if (threads < 1) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        threads = hw ? (int)(hw < 16 ? hw : 16) : 4;
-    }
+    if (threads < 1) threads = Pool::get().size() + 1;
     try {
         if (dims == 2) order_of<2>(h_pos, n, stride, leaf_size, h_order, threads);
         else order_of<3>(h_pos, n, stride, leaf_size, h_order, threads);

@@ -893,6 +893,16 @@ __global__ __launch_bounds__(ZB_THREADS) void zbuffer_count_kernel(
     if (lane == 0) { atomicAdd(&out[0], instr); atomicAdd(&out[1], lanes); atomicAdd(&out[2], ents); }
 }
 
+// out[3] += in-view (point, view) pairs of the call: the records the count pass staged.
+__global__ __launch_bounds__(256) void staged_total_kernel(
+    const unsigned *__restrict__ staged_count, i64 blocks, u64 *__restrict__ out)
+{
+    u64 s = 0;
+    for (i64 k = (i64)blockIdx.x * 256 + threadIdx.x; k < blocks; k += (i64)gridDim.x * 256) s += staged_count[k];
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&out[3], s);
+}
+
 // ------------------------------------------------------------------------- //
 // exact mode for the single-view API: stamp splat centres of seen points      //
 // ------------------------------------------------------------------------- //
@@ -1993,7 +2003,8 @@ extern "C" size_t mvf_map_images_workspace_bytes(
 
 // LDS-atomic work of the z-buffer pass of the mvf_map_images_exact call that
 // last used `workspace` (same sizes): d_out[0..2] += wave-instructions, lane
-// atomics, entries (see zbuffer_count_kernel).
+// atomics, entries (see zbuffer_count_kernel); d_out[3] += in-view (point, view)
+// pairs (the records the count pass staged).
 extern "C" int mvf_profile_zbuffer_ops(
     void *workspace, size_t workspace_bytes, int64_t n, int32_t V, const mvf_vis_params *h_params,
     int64_t num_points, int64_t pair_capacity, int64_t centre_slots, uint64_t *d_out, void *stream)
@@ -2011,6 +2022,9 @@ extern "C" int mvf_profile_zbuffer_ops(
     hipLaunchKernelGGL(zbuffer_count_kernel, dim3(zb_grid(tiles)), dim3(ZB_THREADS), 0, (hipStream_t)stream,
                        ws.entries, ws.descs, ws.tile_count + ws.ncnt, (i64)pair_capacity, (u64 *)d_out,
                        (unsigned)tiles);
+    const i64 staged_blocks = (i64)V * cdiv(n, 256);
+    hipLaunchKernelGGL(staged_total_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, ws.staged_count,
+                       staged_blocks, (u64 *)d_out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }

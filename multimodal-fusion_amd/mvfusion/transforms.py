@@ -705,26 +705,18 @@ class MapImages(ImageTransform):
         cached = getattr(data, '_mvf_staged', None)
         if cached is not None and _same_sources(cached[0], str(device), src):
             return cached[1]
+        if N == 0:
+            return None
         if not ids.is_cuda:
-            # host ids: range and distinctness are settled here, without a device round trip
-            ids_h = np.asarray(ids.detach(), dtype=np.int64)
-            lo, hi = (int(ids_h.min()), int(ids_h.max())) if N else (0, -1)
-            num_points = hi + 1
-            if lo < 0:
-                return None
-            inv_h = np.full(num_points, -1, dtype=np.int64)
-            src_h = np.arange(N, dtype=np.int64)
-            if order is not None:            # position of every point in the local order
-                src_h = np.empty(N, dtype=np.int64)
-                src_h[np.asarray(order.cpu(), dtype=np.int64)] = np.arange(N, dtype=np.int64)
-            inv_h[ids_h] = src_h
-            if int((inv_h >= 0).sum()) != N:
-                return None      # repeated mapping ids: several pixels per (point, view)
-            inv = torch.from_numpy(inv_h).to(device, non_blocking=True)
-            ids = ids.to(device=device, dtype=torch.int64, non_blocking=True)
+            # host ids: their range is settled here, without a device round trip
+            ids_h = np.asarray(ids.detach())
+            lo, hi = int(ids_h.min()), int(ids_h.max())
         else:
-            inv = None
-            ids = ids.to(device=device, dtype=torch.int64)
+            lo, hi = (int(v) for v in torch.aminmax(ids))
+        if lo < 0:
+            return None
+        num_points = hi + 1
+        ids = ids.to(device=device, dtype=torch.int64, non_blocking=True)
         pos = data.pos.to(device=device, dtype=torch.float32, non_blocking=True)
         attrs = [getattr(data, k, None) for k in names]
         attrs = [a.to(device=device, dtype=torch.float32, non_blocking=True) if a is not None else None
@@ -733,12 +725,12 @@ class MapImages(ImageTransform):
             order = order.to(device, non_blocking=True)
             pos, ids = pos[order], ids[order]
             attrs = [a[order] if a is not None else None for a in attrs]
-        if inv is None:
-            num_points = int(ids.max().item()) + 1
-            inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
-            inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
-            if int((inv >= 0).sum().item()) != N or int(ids.min().item()) < 0:
-                return None      # repeated mapping ids: several pixels per (point, view)
+        # position of every mapping id in the local order; ids must be distinct (repeated
+        # ids mean several pixels per (point, view), which the per-view path handles)
+        inv = torch.full((num_points,), -1, dtype=torch.int64, device=device)
+        inv[ids] = torch.arange(N, dtype=torch.int64, device=device)
+        if int((inv >= 0).sum()) != N:
+            return None
         staged = (pos.contiguous(), ids.contiguous(), inv,
                   [a.contiguous() if a is not None else None for a in attrs], num_points)
         try:

@@ -4,14 +4,25 @@ FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte reque
 as 64 bytes for wide streaming reads, so it is doubled (an upper bound for
 narrow reads).
 usage: python profiles/make_traffic.py <cfg> <fetch_dir> <write_dir> [output.json]
-(default output: profiles/pmc_traffic.json).  "step" = all kernels of one bench step
-(one launch of the first mapping kernel each), "forward" = one QKVBimodalCSRPool forward."""
+(default output: profiles/pmc_traffic.json).  "step" = the kernels of one bench step: the
+per-launch average of every kernel of the workload's pipeline times its launches per step
+(kernels that only run while the inputs are set up, such as the rendering of the depth maps
+of c5, are not part of a step); "forward" = one QKVBimodalCSRPool forward."""
 import collections
 import csv
 import glob
 import json
 import os
 import sys
+
+# kernels of one step of a mapping workload and their launches per step
+EXACT = {"bin_count_kernel": 1, "tile_scan_kernel": 1, "bin_fill_kernel": 1, "tile_zbuffer_kernel": 1,
+         "mi_centre_kernel": 1, "mi_point_mask_kernel": 1, "mi_fill_kernel": 1, "two_level_pool_kernel": 1}
+DEPTH = {"mi_point_mask_kernel": 1, "mi_fill_kernel": 1, "two_level_pool_kernel": 1}
+SPLAT = {"bin_count_kernel": 1, "tile_scan_kernel": 1, "bin_fill_kernel": 1, "tile_zbuffer_kernel": 1,
+         "ne_scan_kernel": 2, "ne_point_kernel": 1, "ne_fill_kernel": 1, "segment_long_kernel": 1,
+         "two_level_pool_kernel": 1}
+PIPELINE = {"c1": EXACT, "c2": EXACT, "c4": EXACT, "c5": DEPTH, "c2_nonexact": SPLAT}
 
 STAGE = {"bin_count_kernel": "bin_count", "tile_scan_kernel": "tile_scan", "bin_fill_kernel": "bin_fill",
          "tile_zbuffer_kernel": "tile_zbuffer", "mi_centre_kernel": "centre",
@@ -45,13 +56,16 @@ nfwd = len(fetch.get("attention_scores_kernel", []))
 total = sum(2.0 * sum(fetch[k]) + sum(write[k]) for k in set(fetch) | set(write))
 if nfwd:
     out["forward"] = total / nfwd
-nstep = max(len(fetch.get("bin_count_kernel", [])), len(fetch.get("mi_point_mask_kernel", [])))
-if nstep and not nfwd:
-    out["step"] = total / nstep
+if not nfwd:
+    pipe = PIPELINE.get(cfg, EXACT)
+    per_launch = lambda k: 2.0 * sum(fetch[k]) / max(len(fetch[k]), 1) + sum(write[k]) / max(len(write[k]), 1)
+    out["step"] = sum(per_launch(k) * mult for k, mult in pipe.items() if k in fetch or k in write)
+    out["step_kernels"] = sorted(k for k in pipe if k in fetch or k in write)
 path = out_path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 data[cfg] = out
 data[cfg + "_detail"] = detail
 json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 for k, v in out.items():
-    print(f"{k:28s} {v / 1e6:10.2f} MB per launch")
+    if not isinstance(v, list):
+        print(f"{k:28s} {v / 1e6:10.2f} MB per launch")
