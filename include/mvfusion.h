@@ -633,16 +633,21 @@ int mvf_mlp_forward_dot(
  * (cout % G == 0, a multiple of 4 channels per group unless G == 1), and
  * already holds att * gate.  att and pool_out must come from
  * mvf_attention_pool(x_mod = NULL), which folds the gate that way and zeroes
- * the rows the epilogue adds to atomically: segments are folded in row order
- * inside tiles of 32 rows, a segment crossing a tile boundary is the sum of
- * per-tile partial sums.  Results agree with mvf_attention_pool's to float32
- * rounding (bit for bit when there is no gate and the segment lies inside one
- * tile). */
+ * the rows of empty segments.  Segments are folded in row order inside tiles
+ * of 32 rows (the wide chains: as a balanced tree over the tile's rows); a
+ * segment that crosses a tile boundary leaves one partial sum per tile in
+ * `workspace` (mvf_mlp_forward_pool_workspace_bytes(rows, cout)), and a second
+ * launch adds those up in tile order: no atomics, the same bits on every run.
+ * ptr [nseg + 1] and row2seg [rows] describe the same segments.  Results agree
+ * with mvf_attention_pool's to float32 rounding (bit for bit when there is no
+ * gate and the segment lies inside one tile of the float32 chain). */
+size_t mvf_mlp_forward_pool_workspace_bytes(int64_t rows, int32_t cout);
 int mvf_mlp_forward_pool(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    const float *att, int32_t G, const int32_t *row2seg, float *pool_out, void *stream);
+    const float *att, int32_t G, const int32_t *row2seg, const int64_t *ptr, int64_t nseg,
+    float *pool_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same chain (two layers of equal output width <= 64: DeepSetFeat.mlp_elt_1,
  * pooling.py:633; mode 0 inputs without row gathers, 16-byte aligned rows in and

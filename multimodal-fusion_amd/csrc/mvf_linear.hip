@@ -95,12 +95,14 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
         }
     };
 
-    float sum1[STATS ? NO : 1][16], sum2[STATS ? NO : 1][16];
+    // float64 from the first addition on: sum(y^2) / n - mean^2 cancels when a column's mean is
+    // large against its spread, and float32 partial sums would not survive that
+    double sum1[STATS ? NO : 1][16], sum2[STATS ? NO : 1][16];
     if constexpr (STATS) {
 #pragma unroll
         for (int o = 0; o < NO; ++o)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum1[o][e] = sum2[o][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) sum1[o][e] = sum2[o][e] = 0.0;
     }
 
     i64 t = wid;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
             for (int o = 0; o < NO; ++o)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float v = acc[o][e] * live;
+                    const double v = (double)(acc[o][e] * live);
                     sum1[o][e] += v;
                     sum2[o][e] += v * v;
                 }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_linear_kernel(
         for (int o = 0; o < NO; ++o)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                double a = (double)sum1[o][e], b = (double)sum2[o][e];
+                double a = sum1[o][e], b = sum2[o][e];
 #pragma unroll
                 for (int d = 1; d < 32; d <<= 1) {
                     a += __shfl_xor(a, d, 64);

@@ -83,13 +83,19 @@ struct MlpArgs {
     const float *pool_att;
     float *pool_out;
     int pool_groups;
+    // sums (POOL 1 / 2): per-tile partial sums of the segments that cross a tile boundary,
+    // [tile][2][cout]: slot 0 = the segment that began in an earlier tile and ends in this
+    // one, slot 1 = the segment that continues in the next tile (whether or not it began
+    // in this one).  pool_fixup_kernel adds them up in tile order.
+    float *pool_part;
 };
 
 // Rows of one staging step of the pool epilogue and the LDS pitch of a staged row.
 constexpr int POOL_STAGE_ROWS = 16;
 constexpr int POOL_PITCH = MLP_MAX_C + 4;
 // Segments are folded inside tiles of this many rows (one wave's rows); a segment that
-// crosses a tile boundary is completed with atomic adds and must start from zero.
+// crosses a tile boundary leaves one partial sum per tile, which a second launch adds up
+// in tile order (maxima: combined with atomic maxima, which do not depend on order).
 constexpr int POOL_TILE = 32;
 // Most attention groups the pool epilogue takes (their weights of a tile are parked in the
 // staging rows, two groups per lane and load).
@@ -301,14 +307,15 @@ __device__ __forceinline__ void atomic_max_float(float *p, float v)
 // channels of its row (for the sum: times the row's attention weight), then lane c folds
 // channel c over the staged rows in row order.  The segment of a row is wave-uniform (read
 // from the row's lane), so segment changes are scalar branches.  A segment that lies inside
-// the tile is stored; one that continues in a neighbouring tile is combined atomically with
-// its preset row (zeros for the sum, -inf for the maximum).  pseg: the row's segment (-1 past
-// the end), pprev / pnext: the segments of the rows next to the tile, patt: the row's
-// attention weight (POOL 1); POOL 2 finds the tile's [32][groups] weights parked in `stg`.
+// the tile is stored; one that continues in a neighbouring tile leaves its partial sum in
+// the tile's slot of A.pool_part (the maximum: combined atomically with its row preset to
+// -inf).  pseg: the row's segment (-1 past the end), pprev / pnext: the segments of the rows
+// next to the tile, patt: the row's attention weight (POOL 1); POOL 2 finds the tile's
+// [32][groups] weights parked in `stg`.  t0: first row of the tile.
 template <int POOL>
 __device__ __forceinline__ void mlp_pool_tail(
     const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout, float *stg,
-    int pseg, int pprev, int pnext, float patt, int lane)
+    int pseg, int pprev, int pnext, float patt, int lane, i64 t0)
 {
     const int jrow = lane & 31, kh = lane >> 5;
     // rows times their attention weights, in place (POOL == 2: one weight per float4
@@ -346,12 +353,12 @@ __device__ __forceinline__ void mlp_pool_tail(
     // segment kernels); a partial maximum meets the others in a row preset to -inf
     constexpr float FOLD0 = POOL == 3 ? -INFINITY : 0.f;
     float accv = FOLD0;
-    auto flush = [&](int seg, float v, bool part) {
+    auto flush = [&](int seg, float v, bool part, int slot) {
         if (seg < 0 || lane >= cout) return;
         float *o = A.pool_out + (size_t)seg * cout + lane;
         if (!part) *o = v;
         else if (POOL == 3) atomic_max_float(o, v);
-        else unsafeAtomicAdd(o, v);
+        else A.pool_part[((size_t)(t0 / POOL_TILE) * 2 + slot) * cout + lane] = v;
     };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -377,7 +384,7 @@ __device__ __forceinline__ void mlp_pool_tail(
             const int r = half * POOL_STAGE_ROWS + i;
             const int s = __builtin_amdgcn_readlane(pseg, r);
             if (s != cur) {
-                flush(cur, accv, partial);
+                flush(cur, accv, partial, 0);
                 partial = false;
                 cur = s;
                 accv = FOLD0;
@@ -391,7 +398,7 @@ __device__ __forceinline__ void mlp_pool_tail(
     }
     // rows past the end carry segment -1: a tile that holds some has flushed its
     // last segment at the change and ends with cur = -1
-    flush(cur, accv, partial || cur == pnext);
+    flush(cur, accv, partial || cur == pnext, cur == pnext ? 1 : 0);
 }
 
 // The same reduction without LDS and without a serial walk over the rows: a segmented
@@ -401,7 +408,7 @@ __device__ __forceinline__ void mlp_pool_tail(
 // every lane whose segment reaches that far back adds the partial of the lane behind it,
 // for all of its 16 / 32 channel registers.  The last row of a segment then holds the
 // segment's result and writes it with 16-byte stores; a segment that continues in a
-// neighbouring tile is combined atomically as in mlp_pool_tail.  The sum
+// neighbouring tile leaves its partial sum in A.pool_part as in mlp_pool_tail.  The sum
 // of a segment is a balanced tree over its rows instead of the in-order fold (deterministic,
 // same error bound, different last bits for segments of three and more rows).  Sums only
 // (POOL 1 / 2).  Needs cout % 4 == 0 and a 16-byte aligned output.  `stage2`: the wave's
@@ -409,7 +416,7 @@ __device__ __forceinline__ void mlp_pool_tail(
 template <int POOL>
 __device__ __forceinline__ void mlp_pool_tail_scan(
     const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout, float *stage2,
-    int pseg, int pprev, int pnext, float patt, int lane)
+    int pseg, int pprev, int pnext, float patt, int lane, i64 t0)
 {
     static_assert(POOL == 1 || POOL == 2, "sums only");
     const float *att_lds = stage2;
@@ -471,14 +478,15 @@ __device__ __forceinline__ void mlp_pool_tail_scan(
     MVF_SCAN_STEP((jrow & 16) && d > (jrow & 15), "row_bcast:15 row_mask:0xa bank_mask:0xf")
 #undef MVF_SCAN_STEP
     // Segments that continue in a neighbouring tile (at most the first and the last one, known
-    // wave-wide) go through two staging rows so that one atomic instruction adds 64 channels.
+    // wave-wide) leave their partial sums in the tile's two slots of the partial buffer.
     const int seg0 = __builtin_amdgcn_readlane(pseg, 0), seg31 = __builtin_amdgcn_readlane(pseg, 31);
     const bool part1 = seg31 >= 0 && seg31 == pnext;
     const bool part0 = seg0 >= 0 && seg0 == pprev && !(part1 && seg0 == seg31);
     const bool mine_partial = (part0 && pseg == seg0) || (part1 && pseg == seg31);
     if (is_end && pseg >= 0) {
-        float *o = mine_partial ? stage2 + (pseg == seg31 && part1 ? POOL_PITCH : 0) + 4 * kh
-                                : A.pool_out + (size_t)pseg * cout + 4 * kh;
+        float *o = mine_partial
+            ? A.pool_part + ((size_t)(t0 / POOL_TILE) * 2 + (pseg == seg31 && part1 ? 1 : 0)) * cout + 4 * kh
+            : A.pool_out + (size_t)pseg * cout + 4 * kh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (8 * g + 4 * kh < cout)
@@ -486,16 +494,6 @@ __device__ __forceinline__ void mlp_pool_tail_scan(
             if (wide && 32 + 8 * g + 4 * kh < cout)
                 *(float4 *)(o + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
         }
-    }
-    if (part0 || part1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (part0 && lane < cout) unsafeAtomicAdd(A.pool_out + (size_t)seg0 * cout + lane, stage2[lane]);
-        if (part1 && lane < cout) unsafeAtomicAdd(A.pool_out + (size_t)seg31 * cout + lane, stage2[POOL_PITCH + lane]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -878,7 +876,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         if (POOL)
             mlp_pool_tail<POOL>(A, acc0, acc1, cop_of(nlayers - 1) > 32, A.L[nlayers - 1].cout,
                                 smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH),
-                                pseg, pprev, pnext, patt, lane);
+                                pseg, pprev, pnext, patt, lane, base + wave * 32);
     tile_done:;
         CSTAMP(2)
     }
@@ -1253,10 +1251,10 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
         }
         if (POOL == 1 || POOL == 2)
             mlp_pool_tail_scan<POOL == 2 ? 2 : 1>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
-                                                  pseg, pprev, pnext, patt, lane);
+                                                  pseg, pprev, pnext, patt, lane, base + wave * 32);
         else if (POOL == 3)
             mlp_pool_tail<3>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
-                             pseg, pprev, pnext, patt, lane);
+                             pseg, pprev, pnext, patt, lane, base + wave * 32);
 #pragma unroll
         for (int t = 8; t < 8 * NQ0; ++t) xr[t] = xn[t];
         STAMP(2)
@@ -1816,7 +1814,7 @@ static int mlp_forward_impl(
     float *out, int32_t ldo, const float *dot_q, int32_t dot_ldq, const int32_t *dot_seg,
     float dot_div, float *dot_out, void *stream,
     const float *pool_att = nullptr, float *pool_out = nullptr, int32_t pool_groups = 1,
-    bool pool_max = false)
+    bool pool_max = false, float *pool_part = nullptr)
 {
     MVF_REQUIRE(rows >= 0 && layers && nlayers >= 1 && nlayers <= MLP_MAX_LAYERS,
                 "mlp_forward: bad arguments (nlayers=%d)", nlayers);
@@ -1827,7 +1825,8 @@ static int mlp_forward_impl(
         MVF_REQUIRE(dot_seg && !dot_out && out && !gather_a && !gather_b,
                     "mlp_forward_segmax: needs the row output and the row -> segment map, no row gathers");
     } else if (pool_out) {
-        MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out, "mlp_forward_pool: needs the attention weights and the row -> segment map");
+        MVF_REQUIRE(pool_att && dot_seg && !dot_out && !out && pool_part,
+                    "mlp_forward_pool: needs the attention weights, the row -> segment map and the partial-sum buffer");
         MVF_REQUIRE(!gather_a && !gather_b, "mlp_forward_pool: row gathers are not supported");
         const int co = layers[nlayers - 1].cout;
         static_assert(32 * POOL_MAX_GROUPS <= POOL_STAGE_ROWS * POOL_PITCH, "the weights of a tile are parked in its staging rows");
@@ -1871,7 +1870,7 @@ static int mlp_forward_impl(
     A.out = out;
     A.ldo = ldo;
     A.dot_q = dot_q; A.dot_seg = dot_seg; A.dot_ldq = dot_ldq; A.dot_div = dot_div; A.dot_out = dot_out;
-    A.pool_att = pool_att; A.pool_out = pool_out; A.pool_groups = pool_groups;
+    A.pool_att = pool_att; A.pool_out = pool_out; A.pool_groups = pool_groups; A.pool_part = pool_part;
     if (pool_out) A.dot_seg = dot_seg;
     A.debug = 0;
 #ifdef MVF_MLP_DEBUG
@@ -2085,15 +2084,61 @@ extern "C" int mvf_mlp_forward_dot(
                             nlayers, nullptr, 0, queries, ldq, row2seg, divisor, dot_out, stream);
 }
 
+// Sums of the segments that cross a tile boundary, from the per-tile partial sums the pool
+// epilogue left (MlpArgs::pool_part), added in tile order: the first tile's slot 1, the slots
+// 1 of the tiles that lie inside the segment, the last tile's slot 0.  One thread per
+// (segment, 4 channels); segments inside one tile were stored by the epilogue.
+__global__ __launch_bounds__(256) void pool_fixup_kernel(
+    const i64 *__restrict__ ptr, i64 nseg, int cout, const float *__restrict__ part, float *__restrict__ out)
+{
+    const int q = cout >> 2;
+    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nseg * q) return;
+    const i64 s = t / q;
+    const int c = (int)(t - s * q) * 4;
+    const i64 a = ptr[s], b = ptr[s + 1];
+    if (b <= a) return;
+    const i64 ta = a / POOL_TILE, tb = (b - 1) / POOL_TILE;
+    if (ta == tb) return;
+    float4 acc = *(const float4 *)(part + ((size_t)ta * 2 + 1) * cout + c);
+    for (i64 u = ta + 1; u <= tb; ++u) {
+        const float4 v = *(const float4 *)(part + ((size_t)u * 2 + (u == tb ? 0 : 1)) * cout + c);
+        acc.x = __fadd_rn(acc.x, v.x); acc.y = __fadd_rn(acc.y, v.y);
+        acc.z = __fadd_rn(acc.z, v.z); acc.w = __fadd_rn(acc.w, v.w);
+    }
+    *(float4 *)(out + (size_t)s * cout + c) = acc;
+}
+
+extern "C" size_t mvf_mlp_forward_pool_workspace_bytes(int64_t rows, int32_t cout)
+{
+    const size_t tiles = (size_t)((rows > 0 ? rows : 1) + POOL_TILE - 1) / POOL_TILE;
+    return align_up(tiles * 2 * (size_t)(cout > 0 ? cout : 1) * sizeof(float));
+}
+
 extern "C" int mvf_mlp_forward_pool(
     const float *xa, int32_t lda, int32_t cols_a, const int32_t *gather_a,
     const float *xb, int32_t ldb, int32_t cols_b, const int32_t *gather_b,
     int64_t rows, const mvf_mlp_layer *layers, int32_t nlayers,
-    const float *att, int32_t G, const int32_t *row2seg, float *pool_out, void *stream)
+    const float *att, int32_t G, const int32_t *row2seg, const int64_t *ptr, int64_t nseg,
+    float *pool_out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    MVF_REQUIRE(pool_out, "mlp_forward_pool: null output");
-    return mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
-                            nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, pool_out, G);
+    MVF_REQUIRE(pool_out && ptr && nseg >= 0 && layers && nlayers >= 1, "mlp_forward_pool: null output or pointers");
+    const int cout = layers[nlayers - 1].cout;
+    MVF_REQUIRE(cout % 4 == 0 && (uintptr_t)pool_out % 16 == 0,
+                "mlp_forward_pool: a multiple of 4 output channels and a 16-byte aligned output");
+    if (rows == 0 || nseg == 0) return MVF_OK;
+    if (!workspace || workspace_bytes < mvf_mlp_forward_pool_workspace_bytes(rows, cout)) {
+        set_error("mlp_forward_pool: workspace too small");
+        return MVF_E_WORKSPACE;
+    }
+    if (int rc = mlp_forward_impl(xa, lda, cols_a, gather_a, xb, ldb, cols_b, gather_b, 0, rows, layers,
+                                  nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, pool_out, G,
+                                  false, (float *)workspace))
+        return rc;
+    hipLaunchKernelGGL(pool_fixup_kernel, dim3(cdiv(nseg * (cout / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const i64 *)ptr, (i64)nseg, cout, (const float *)workspace, pool_out);
+    MVF_LAUNCH_CHECK();
+    return MVF_OK;
 }
 
 extern "C" int mvf_mlp_forward_segmax(

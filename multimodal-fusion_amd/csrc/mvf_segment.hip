@@ -105,8 +105,10 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
 // its chain of loads.  Here a wave takes a segment: lane = (row group, channel)
 // with 64 >> cp_log row groups of 1 << cp_log >= min(C, 64) channels, four steps
 // of rows in flight, and a final combine across the row groups.  Ties (+0.0 /
-// -0.0 compare equal) go to the first row, as in the in-order fold, so the
-// result is bit-identical to segment_csr_kernel's.
+// -0.0 compare equal) go to the first row, as in the in-order fold, and a NaN
+// counts where that fold counts it (it sticks when it is the segment's first
+// row and is passed over anywhere else: every comparison with it is false), so
+// the result is bit-identical to segment_csr_kernel's.
 template <int MODE>
 __global__ __launch_bounds__(256) void segment_long_kernel(
     const float *__restrict__ src, int C, int cp_log, const i64 *__restrict__ ptr, i64 nseg,
@@ -135,15 +137,20 @@ __global__ __launch_bounds__(256) void segment_long_kernel(
                 x[k] = ok[k] ? q[(size_t)(r + (unsigned)(k * rp)) * C] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (ok[k] && (at == 0xffffffffu || better(x[k], acc))) { acc = x[k]; at = r + (unsigned)(k * rp); }
+            for (int k = 0; k < 4; ++k) {
+                const unsigned rk = r + (unsigned)(k * rp);
+                // a lane starts from its first number (or from row 0, whatever it holds)
+                const bool start = at == 0xffffffffu && (x[k] == x[k] || rk == 0u);
+                if (ok[k] && (start || better(x[k], acc))) { acc = x[k]; at = rk; }
+            }
         }
         // combine the row groups (lane bits cp_log .. 5)
         for (int d = 32; d >= cp; d >>= 1) {
             const float ov = __shfl_xor(acc, d, 64);
             const unsigned oat = __shfl_xor(at, d, 64);
-            const bool take = oat != 0xffffffffu &&
-                (at == 0xffffffffu || better(ov, acc) || (!better(acc, ov) && oat < at));
+            // (only row 0 can have left a NaN: it wins over everything)
+            const bool take = oat != 0xffffffffu && acc == acc &&
+                (at == 0xffffffffu || ov != ov || better(ov, acc) || (!better(acc, ov) && oat < at));
             if (take) { acc = ov; at = oat; }
         }
         if (ro == 0 && live) out[(size_t)seg * C + ch] = at == 0xffffffffu ? 0.f : acc;

@@ -129,8 +129,9 @@ _SIGNATURES = {
                                   _P, _I32, _P]),
     "mvf_mlp_forward_dot": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I32, _I64, _P, _I32,
                                       _P, _I32, _P, _F, _P, _P]),
+    "mvf_mlp_forward_pool_workspace_bytes": (_SZ, [_I64, _I32]),
     "mvf_mlp_forward_pool": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _P, _I64, _P, _I32,
-                                       _P, _I32, _P, _P, _P]),
+                                       _P, _I32, _P, _P, _I64, _P, _P, _SZ, _P]),
     "mvf_mlp_forward_segmax": (C.c_int, [_P, _I32, _I32, _P, _I32, _I32, _I64, _P, _I32, _P, _I32,
                                          _P, _I64, _P, _P, _P]),
     "mvf_attention_pool": (C.c_int, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I64, _I32,

@@ -92,7 +92,7 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     of (LayerSpec, lo, hi); out = tensor view whose first element is the
     output's first column, ldo_tensor = row stride in floats.  dot = (queries,
     row2seg, divisor): mvf_mlp_forward_dot, `out` is the [rows] dot output.
-    pool = (att, row2seg): mvf_mlp_forward_pool, `out` is the prepared
+    pool = (att, row2seg, ptr): mvf_mlp_forward_pool, `out` is the prepared
     [nseg, cout] pool output."""
     lib = L.load()
     xa, ga, xb, gb, mode = src
@@ -115,12 +115,14 @@ def _launch(src, specs, cols, out, ldo_tensor, dot=None, pool=None):
     dev = xa.device
     with torch.cuda.device(dev):
         if pool is not None:
-            att, seg = pool
+            att, seg, ptr = pool
+            # per-tile partial sums of the segments that cross a 32-row tile
+            ws = L.workspace(lib.mvf_mlp_forward_pool_workspace_bytes(rows, specs[-1][2] - specs[-1][1]), dev)
             L.check(lib.mvf_mlp_forward_pool(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
                 L.ptr(xb), 0 if xb is None else xb.stride(0), 0 if xb is None else xb.shape[1],
                 L.ptr(gb), rows, arr, len(specs), L.ptr(att), att.shape[1], L.ptr(seg),
-                L.ptr(out), L.stream_ptr(dev)))
+                L.ptr(ptr), ptr.shape[0] - 1, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr(dev)))
         elif dot is None:
             L.check(lib.mvf_mlp_forward(
                 L.ptr(xa), xa.stride(0), xa.shape[1], L.ptr(ga),
@@ -247,12 +249,13 @@ def pool_fusable(specs, x, num_groups):
             and x.shape[0] > 0)
 
 
-def pooled_layers(specs, x, att, row2seg, out):
+def pooled_layers(specs, x, att, row2seg, ptr, out):
     """out[s] = sum_{r in s} specs(x)[r] * att[r]: the layer chain with the pool
     epilogue (needs pool_fusable; `att` [rows, G] and `out` as returned by
-    attention_pool(<number of channels>, ...): that `att` carries the gate)."""
+    attention_pool(<number of channels>, ...): that `att` carries the gate).
+    ptr [nseg + 1] int64: the CSR pointers row2seg was made from."""
     _launch((x.detach(), None, None, None, 0), [(sp, 0, sp.cout) for sp in specs], None, out,
-            specs[-1].cout, pool=(att, row2seg))
+            specs[-1].cout, pool=(att, row2seg, ptr))
     return out
 
 

@@ -122,13 +122,21 @@ class ImageMapping(CSRData):
         rows = point_ids.shape[0]
         if rows > 0 and pixels.dtype == torch.int16 and (features is None or features.dim() == 2):
             # one launch set on the device: key per row, radix sort, CSR assembly
-            p_max, i_max = torch.stack([point_ids.max(), image_ids.max()]).tolist()
-            n_pts = max(int(num_points or 0), int(p_max) + 1)
-            if _device_assembly_fits(pixels, rows, n_pts, int(i_max) + 1):
+            # one read-back: the ranges of the ids and of the pixel coordinates.  The device
+            # keys hold ids and coordinates as unsigned fields: anything negative takes the
+            # host-ordered composition below
+            lims = torch.stack([*torch.aminmax(point_ids), *torch.aminmax(image_ids),
+                                pixels.min().to(torch.int64)]).tolist()
+            p_min, p_max, i_min, i_max, pix_min = (int(v) for v in lims)
+            n_pts = max(int(num_points or 0), p_max + 1)
+            if min(p_min, i_min, pix_min) >= 0 and _device_assembly_fits(pixels, rows, n_pts, i_max + 1):
                 arrays = _csr_from_dense_rows(
-                    point_ids, image_ids, pixels, features, n_pts, int(i_max) + 1)
+                    point_ids, image_ids, pixels, features, n_pts, i_max + 1)
+                feats = arrays[4]
+                if feats is not None and features.dtype != feats.dtype and features.dtype.is_floating_point:
+                    feats = feats.to(features.dtype)       # computed in float32, returned as given
                 return ImageMapping.from_csr_arrays(
-                    arrays[0], arrays[1], arrays[3], arrays[4], arrays[2]).to(in_device)
+                    arrays[0], arrays[1], arrays[3], feats, arrays[2]).to(in_device)
 
         order = lexargsort(point_ids, image_ids, pixels[:, 0], pixels[:, 1])
         point_ids, image_ids, pixels = point_ids[order], image_ids[order], pixels[order]
@@ -141,8 +149,11 @@ class ImageMapping(CSRData):
         image_ids = image_ids[last]
         point_ids = point_ids[last]
         if features is not None:
+            in_dtype = features.dtype
             features = _pooling.segment_csr(
                 features.float(), image_pixel_mappings.pointers, reduce='mean')
+            if in_dtype.is_floating_point and in_dtype != features.dtype:
+                features = features.to(in_dtype)
             mapping = ImageMapping(
                 point_ids, image_ids, image_pixel_mappings, features, dense=True,
                 is_index_value=[True, False, False])
@@ -255,8 +266,12 @@ class ImageMapping(CSRData):
             return self.clone()
 
         n_new = int(idx.max()) + 1
-        n_img = int(self.images.max()) + 1
-        if _device_assembly_fits(self.pixels, self.pixels.shape[0], n_new, n_img) \
+        i_max, i_min, pix_min = torch.stack(
+            [self.images.max(), self.images.min(), self.pixels.min().to(torch.int64)]).tolist()
+        n_img = int(i_max) + 1
+        # (the device keys hold image ids and pixel coordinates as unsigned fields)
+        if min(int(i_min), int(pix_min)) >= 0 \
+                and _device_assembly_fits(self.pixels, self.pixels.shape[0], n_new, n_img) \
                 and self.num_items < 2 ** 31:
             return self._merge_points_device(idx, n_new, n_img)
 

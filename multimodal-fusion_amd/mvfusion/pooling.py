@@ -826,7 +826,7 @@ class GroupBimodalCSRPool(_AttentivePool):
             gate_w=None if self.G is None else self.G.weight,
             gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
         if fuse_pool:
-            _dense.pooled_layers(e_mod, x_mod, att, row2seg, x_pool)
+            _dense.pooled_layers(e_mod, x_mod, att, row2seg, ptr, x_pool)
         if self.save_last:
             self._last_x_map = x_map
             self._last_x_mod = x_mod
@@ -953,7 +953,7 @@ class QKVBimodalCSRPool(_AttentivePool):
             gate_w=None if self.G is None else self.G.weight,
             gate_b=None if self.G is None else self.G.bias, gating=self.G is not None)
         if fuse_pool:
-            _dense.pooled_layers(e_mod, x_mod, att, row2seg, x_pool)
+            _dense.pooled_layers(e_mod, x_mod, att, row2seg, ptr, x_pool)
 
         if self.save_last:
             self._last_x_map = x_map

@@ -10,6 +10,8 @@ import os
 import sys
 import tempfile
 
+import zlib
+
 import numpy as np
 import torch
 
@@ -581,7 +583,7 @@ def gen_attention_pools():
                            group_scaling=False, use_num=False),
     }
     for name, kw in variants.items():
-        gen = torch.Generator().manual_seed(hash(name) % 1000)
+        gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # (hash() is salted per process)
         torch.manual_seed(sum(map(ord, name)))
         mod = pooling.QKVBimodalCSRPool(
             in_main=F_main, in_map=F_map, in_mod=C, out_mod=C, save_last=True,

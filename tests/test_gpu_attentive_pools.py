@@ -57,7 +57,7 @@ def _close(got, want, rtol=1e-5):
 
 
 @pytest.mark.parametrize("name", ["qkv_default", "qkv_groups4", "qkv_nogate"])
-def test_qkv_pool_golden(golden, name):
+def test_qkv_pool_golden(golden, name, mlp_precision):
     g = golden(name)
     mod = pooling.QKVBimodalCSRPool(
         in_main=g["x_main"].shape[1], in_map=g["x_map"].shape[1], in_mod=g["x_mod"].shape[1],
@@ -81,7 +81,7 @@ def test_qkv_pool_golden(golden, name):
     _close(out2, g["x_pool"])
 
 
-def test_group_pool_golden(golden):
+def test_group_pool_golden(golden, mlp_precision):
     g = golden("group_pool")
     mod = pooling.GroupBimodalCSRPool(
         in_map=g["x_map"].shape[1], in_mod=g["x_mod"].shape[1], out_mod=g["x_mod"].shape[1],
@@ -96,7 +96,7 @@ def test_group_pool_golden(golden):
 
 @pytest.mark.parametrize("name", ["qkv_usemod", "qkv_minmax", "qkv_residual", "qkv_both",
                                   "group_usemod"])
-def test_attention_variants_golden(golden, name):
+def test_attention_variants_golden(golden, name, mlp_precision):
     """Options beyond the defaults: modality features mixed into keys / queries /
     scores, MinMaxDiffSetFeat / MLPSetFeat encoders, the other fusions and pools."""
     import ast
@@ -144,7 +144,7 @@ def _ptr(rng, n, mean):
     (13, "min", "both", 13, 13),          # odd widths, one group per channel
     (2, "max", "concatenation", 160, 96),  # layers wider than one launch
 ])
-def test_qkv_pool_vs_oracle(groups, pool, fusion, in_mod, out_mod):
+def test_qkv_pool_vs_oracle(groups, pool, fusion, in_mod, out_mod, mlp_precision):
     rng = np.random.default_rng(5)
     N = 20000
     ptr = _ptr(rng, N, 4)
@@ -165,7 +165,7 @@ def test_qkv_pool_vs_oracle(groups, pool, fusion, in_mod, out_mod):
     _close(out, want)
 
 
-def test_group_pool_vs_oracle_and_empty():
+def test_group_pool_vs_oracle_and_empty(mlp_precision):
     rng = np.random.default_rng(6)
     N = 5000
     ptr = _ptr(rng, N, 3)
@@ -184,7 +184,7 @@ def test_group_pool_vs_oracle_and_empty():
     assert z.shape == (7, 32) and float(z.abs().max()) == 0.0
 
 
-def test_deep_set_feat_vs_oracle():
+def test_deep_set_feat_vs_oracle(mlp_precision):
     rng = np.random.default_rng(7)
     ptr = _ptr(rng, 3000, 5)
     x = rng.random((int(ptr[-1]), 8)).astype(np.float32)
@@ -260,7 +260,8 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
     identical bits (without a gate) for every segment inside one 32-row tile (wide chains: of at
     most two rows, their sums are trees), 1e-6 of the output
     scale for the segments that cross a tile boundary; empty segments, segments of
-    more than 64 rows (three tiles) and a ragged last tile included.  A gate is
+    more than 64 rows (three tiles) and a ragged last tile included; two runs give
+    the same bits for every segment.  A gate is
     folded into the attention weights, so with one every segment is compared at
     1e-6.  Then the two modules that use it, with and
     without save_last (which keeps the unfused launches)."""
@@ -294,7 +295,7 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
             assert torch.equal(att2, att)
         else:
             assert torch.equal(att2, att * gate[row2seg.long()])
-        return dense.pooled_layers(specs, x_mod, att2, row2seg, out)
+        return dense.pooled_layers(specs, x_mod, att2, row2seg, dptr, out)
 
     fused, again = fused_pass(), fused_pass()
     assert fused.shape == plain.shape == (N, C) and float(plain.abs().max()) > 0.01
@@ -311,9 +312,10 @@ def test_mlp_chain_pool_epilogue(C, gating, G):
         assert torch.equal(fused[ms], plain[ms])
     _close(fused, plain.cpu().numpy(), rtol=1e-6)
     assert float(fused[T(counts == 0)].abs().max()) == 0.0
-    # run to run: only sums of three or more tile partials may change bits
-    m2 = torch.from_numpy(inside | two_tiles).to(DEV)
-    assert torch.equal(fused[m2], again[m2])
+    # run to run: every segment keeps its bits (the partial sums of the tiles a segment
+    # crosses are added in tile order by a second launch, not atomically)
+    assert two_tiles.sum() > 100 and (~(inside | two_tiles)).sum() >= 2
+    assert torch.equal(fused, again)
 
     # the modules: save_last keeps the unfused launches (and sums the key / score
     # layers' inputs in another order, so no bit equality here)

@@ -143,6 +143,39 @@ def test_segment_csr_long_segments(mode):
     np.testing.assert_allclose(N(got[1]), orc.segment_csr(mid, optr, "mean"), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("mode", ["max", "min"])
+def test_segment_csr_nan_rows_long_equals_short_kernel(mode):
+    """Rows that hold a NaN: the in-order fold of the reference's segment reduction keeps a
+    NaN only when it is the first row of a segment (every comparison with it is false), and
+    passes it over anywhere else.  The wave-per-segment kernel (long segments) returns the
+    same bits as that fold, computed here row by row in numpy and by the thread-per-value
+    kernel (the same segments padded with empty ones, so that the average length is short)."""
+    from mvfusion.pooling import segment_csr
+    rng = np.random.default_rng(23)
+    nseg = 800
+    sizes = rng.integers(17, 150, nseg)
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    for C_ in (1, 13, 64):
+        x = rng.normal(size=(int(ptr[-1]), C_)).astype(np.float32)
+        x[rng.random(x.shape) < 0.05] = np.nan
+        first = ptr[:-1]
+        x[first[rng.random(nseg) < 0.3]] = np.nan             # whole first rows
+        x[first[::7] + 1] = np.nan                            # and second rows
+        want = np.empty((nseg, C_), np.float32)
+        for s_ in range(nseg):
+            acc = x[ptr[s_]].copy()
+            for r in range(ptr[s_] + 1, ptr[s_ + 1]):
+                take = x[r] > acc if mode == "max" else x[r] < acc
+                acc = np.where(take, x[r], acc)
+            want[s_] = acc
+        got_long = N(segment_csr(T(x), T(ptr), reduce=mode))
+        assert np.array_equal(got_long.view(np.uint32), want.view(np.uint32)), C_
+        # the same segments among 20 empty ones each: the serial kernel
+        sparse = np.concatenate([np.repeat(ptr[:-1], 20), ptr[-1:]]).astype(np.int64)
+        got_short = N(segment_csr(T(x), T(sparse), reduce=mode))[19::20]
+        assert np.array_equal(got_short.view(np.uint32), want.view(np.uint32)), C_
+
+
 @pytest.mark.parametrize("inner", ["max", "mean", "min", "sum"])
 def test_segment_csr_two_level_equals_two_passes(inner):
     """One-pass two-level pool == two segment_csr calls, bit for bit, and == the
@@ -505,3 +538,27 @@ def test_image_stats_large(n_img, dtype):
     boxes = m.bounding_boxes
     assert boxes[0].dtype == m.pixels.dtype and boxes[0].shape[0] == int(images.max()) + 1
     assert np.array_equal(boxes[1].cpu().numpy(), want[:int(images.max()) + 1, 2].astype(dtype))
+
+
+def test_from_dense_negative_coordinates_and_feature_dtype():
+    """Rows the device assembly cannot key (negative pixel coordinates: its keys hold them as
+    unsigned fields) take the host-ordered composition and come out in signed (x, y) order:
+    the result equals that of the same rows shifted into the positive range.  Features come
+    back in the dtype they were given in."""
+    from mvfusion.mapping import ImageMapping
+    rng = np.random.default_rng(3)
+    rows, n_pts = 4000, 300
+    pid = rng.integers(0, n_pts, rows)
+    iid = rng.integers(0, 4, rows)
+    pix = rng.integers(-50, 50, (rows, 2)).astype(np.int16)
+    feat = rng.random((rows, 3))
+    # distinct (point, image, pixel) rows
+    _, keep = np.unique(np.stack([pid, iid, pix[:, 0], pix[:, 1]], 1), axis=0, return_index=True)
+    pid, iid, pix, feat = pid[keep], iid[keep], pix[keep], feat[keep]
+    neg = ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
+    pos = ImageMapping.from_dense(T(pid), T(iid), T(pix + np.int16(100)), T(feat), num_points=n_pts)
+    assert neg.features.dtype == pos.features.dtype == torch.float64
+    assert torch.equal(neg.pointers, pos.pointers) and torch.equal(neg.images, pos.images)
+    assert torch.equal(neg.values[1].pointers, pos.values[1].pointers)
+    assert torch.equal(neg.pixels + 100, pos.pixels)
+    assert torch.allclose(neg.features, pos.features, rtol=1e-6, atol=0)

@@ -387,6 +387,35 @@ def test_linear_rows_column_sums_feed_batch_norm(rows, cin, cout):
         assert close(after[k].cpu().numpy(), bn.state_dict()[k].cpu().numpy(), 1e-6)
 
 
+def test_batch_statistics_of_a_large_mean_small_spread_column():
+    """A column whose mean is 1000 times its standard deviation: sum(y^2) / n - mean^2 cancels
+    six digits, so the column sums must be float64 from the first addition on.  The streaming
+    Linear's sums (rows >= 4096, the path that feeds BatchNorm) and the row-reading BatchNorm
+    kernel both reproduce torch.nn.BatchNorm1d's batch variance and output."""
+    from mvfusion import training, pooling
+    torch.manual_seed(5)
+    rows, cin, cout = 200_000, 16, 32
+    x = torch.randn(rows, cin, device="cuda") * 0.01
+    x[:, 0] = 1.0                                   # a constant input column ...
+    seq = pooling.MLP([cin, cout], bias=False).cuda().train()
+    with torch.no_grad():
+        seq[0][0].weight[:, 0] = 10.0               # ... gives every output column the mean 10
+    lin, bn = seq[0][0], seq[0][1].batch_norm
+    z = torch.nn.functional.linear(x, lin.weight)
+    assert float((z.mean(0).abs() / z.std(0)).min()) > 300
+    ref_bn = torch.nn.BatchNorm1d(cout).cuda().train()
+    ref_bn.load_state_dict(bn.state_dict())
+    want = torch.nn.functional.leaky_relu(ref_bn(z.double().float()), seq[0][2].negative_slope)
+    var64 = z.double().var(0, unbiased=True)
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+    for fused in (True, False):
+        bn.load_state_dict(state)
+        y = training.mlp(seq, x) if fused else training.batch_norm_act(training.linear(lin, x), bn, seq[0][2])
+        got_var = (bn.running_var - 0.9 * state["running_var"]) / 0.1
+        assert float(((got_var.double() - var64).abs() / var64).max()) < 1e-4, fused
+        assert float((y - want).abs().max()) < 2e-3 * float(want.abs().max()), fused
+
+
 @pytest.mark.parametrize("D,G", [(16, 1), (8, 4), (8, 1), (4, 8), (6, 2)])
 def test_segment_dot_and_its_gradients(D, G):
     """training.segment_dot (a view's key against the query of its point, per group) against the
