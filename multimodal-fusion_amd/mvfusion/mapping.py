@@ -122,14 +122,17 @@ class ImageMapping(CSRData):
         rows = point_ids.shape[0]
         if rows > 0 and pixels.dtype == torch.int16 and (features is None or features.dim() == 2):
             # one launch set on the device: key per row, radix sort, CSR assembly
-            # one read-back: the ranges of the ids and of the pixel coordinates.  The device
-            # keys hold ids and coordinates as unsigned fields: anything negative takes the
-            # host-ordered composition below
+            # one read-back: the ranges of the ids and of the pixel coordinates.  Ids and
+            # coordinates are unsigned fields of the sort keys (here and, through
+            # max(abs) + 1 digits, in the composite keys of the reference, utils/multimodal.py:13-48)
             lims = torch.stack([*torch.aminmax(point_ids), *torch.aminmax(image_ids),
                                 pixels.min().to(torch.int64)]).tolist()
             p_min, p_max, i_min, i_max, pix_min = (int(v) for v in lims)
+            if min(p_min, i_min, pix_min) < 0:
+                raise ValueError("ImageMapping.from_dense: point ids, image ids and pixel coordinates "
+                                 f"must not be negative (minima {p_min}, {i_min}, {pix_min})")
             n_pts = max(int(num_points or 0), p_max + 1)
-            if min(p_min, i_min, pix_min) >= 0 and _device_assembly_fits(pixels, rows, n_pts, i_max + 1):
+            if _device_assembly_fits(pixels, rows, n_pts, i_max + 1):
                 arrays = _csr_from_dense_rows(
                     point_ids, image_ids, pixels, features, n_pts, i_max + 1)
                 feats = arrays[4]

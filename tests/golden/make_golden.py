@@ -596,10 +596,14 @@ def gen_attention_pools():
             with contextlib.redirect_stdout(io.StringIO()):
                 out = mod(T(x_main), T(x_mod), T(x_map), T(ptr))
         sd = {"sd." + k: v.numpy() for k, v in mod.state_dict().items()}
+        last = dict(C=mod._last_C.numpy(), A=mod._last_A.numpy(),
+                    G=np.zeros(0) if mod.G is None else mod._last_G.numpy())
+        # the same module evaluated in float64: how far the reference's own float32 result is
+        # from the exact one (a nearly closed gate leaves small, cancelling outputs)
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out64 = mod.double()(T(x_main).double(), T(x_mod).double(), T(x_map).double(), T(ptr))
         save(name, x_main=x_main, x_mod=x_mod, x_map=x_map, ptr=ptr,
-             x_pool=out.numpy(),
-             C=mod._last_C.numpy(), A=mod._last_A.numpy(),
-             G=np.zeros(0) if mod.G is None else mod._last_G.numpy(),
+             x_pool=out.numpy(), x_pool64=out64.numpy(), **last,
              **{k: np.asarray(v) for k, v in kw.items()}, **sd)
 
     # flagship-like Group pool (conf/models/.../sparseconv3d.yaml:7320-7328)

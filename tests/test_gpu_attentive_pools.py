@@ -56,9 +56,26 @@ def _close(got, want, rtol=1e-5):
     return worst_rel, worst_abs
 
 
+def _fixture_rtol(g):
+    """Tolerance against a fixture's float32 output: 1e-5, unless the fixture shows that the
+    reference's own float32 result is farther than a third of that from the same module
+    evaluated in float64 (x_pool64) -- then three times that distance: two float32
+    evaluations that are each that far from the exact value cannot be expected to be closer
+    to each other.  (qkv_default: a nearly closed gate leaves outputs of 1e-2 that are
+    cancelling sums; the reference's float32 forward is 1.1e-5 from its float64 one.)"""
+    if "x_pool64" not in g:
+        return 1e-5
+    want = np.asarray(g["x_pool64"], np.float64)
+    big = np.abs(want) > 0.1 * np.abs(want).max()
+    noise = float((np.abs(g["x_pool"] - want)[big] / np.abs(want[big])).max())
+    return max(1e-5, 3.0 * noise)
+
+
 @pytest.mark.parametrize("name", ["qkv_default", "qkv_groups4", "qkv_nogate"])
 def test_qkv_pool_golden(golden, name, mlp_precision):
     g = golden(name)
+    rtol = _fixture_rtol(g)
+    assert rtol < 4e-5 and (name == "qkv_default" or rtol == 1e-5)
     mod = pooling.QKVBimodalCSRPool(
         in_main=g["x_main"].shape[1], in_map=g["x_map"].shape[1], in_mod=g["x_mod"].shape[1],
         out_mod=g["x_mod"].shape[1], num_groups=int(g["num_groups"]), nc_qk=int(g["nc_qk"]),
@@ -69,7 +86,7 @@ def test_qkv_pool_golden(golden, name, mlp_precision):
     assert not missing.missing_keys and not missing.unexpected_keys
     mod = mod.to(DEV).eval()
     out = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
-    _close(out, g["x_pool"])
+    _close(out, g["x_pool"], rtol=rtol)
     _close(mod._last_C, g["C"], rtol=1e-4)
     _close(mod._last_A, g["A"], rtol=1e-4)
     if bool(g["gating"]):
@@ -78,7 +95,9 @@ def test_qkv_pool_golden(golden, name, mlp_precision):
     # differs in the order the key projection sums its input channels
     mod.save_last = False
     out2 = mod(T(g["x_main"]), T(g["x_mod"]), T(g["x_map"]), T(g["ptr"]))
-    _close(out2, g["x_pool"])
+    _close(out2, g["x_pool"], rtol=rtol)
+    # and both are as close to the float64 evaluation as the reference's float32 one is
+    _close(out2, g["x_pool64"], rtol=rtol)
 
 
 def test_group_pool_golden(golden, mlp_precision):

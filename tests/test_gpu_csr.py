@@ -541,24 +541,23 @@ def test_image_stats_large(n_img, dtype):
 
 
 def test_from_dense_negative_coordinates_and_feature_dtype():
-    """Rows the device assembly cannot key (negative pixel coordinates: its keys hold them as
-    unsigned fields) take the host-ordered composition and come out in signed (x, y) order:
-    the result equals that of the same rows shifted into the positive range.  Features come
+    """Negative ids or pixel coordinates are refused (they are unsigned fields of the sort
+    keys; the reference's composite keys do not order them either), and the features come
     back in the dtype they were given in."""
     from mvfusion.mapping import ImageMapping
     rng = np.random.default_rng(3)
     rows, n_pts = 4000, 300
     pid = rng.integers(0, n_pts, rows)
     iid = rng.integers(0, 4, rows)
-    pix = rng.integers(-50, 50, (rows, 2)).astype(np.int16)
+    pix = rng.integers(0, 100, (rows, 2)).astype(np.int16)
     feat = rng.random((rows, 3))
-    # distinct (point, image, pixel) rows
     _, keep = np.unique(np.stack([pid, iid, pix[:, 0], pix[:, 1]], 1), axis=0, return_index=True)
     pid, iid, pix, feat = pid[keep], iid[keep], pix[keep], feat[keep]
-    neg = ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
-    pos = ImageMapping.from_dense(T(pid), T(iid), T(pix + np.int16(100)), T(feat), num_points=n_pts)
-    assert neg.features.dtype == pos.features.dtype == torch.float64
-    assert torch.equal(neg.pointers, pos.pointers) and torch.equal(neg.images, pos.images)
-    assert torch.equal(neg.values[1].pointers, pos.values[1].pointers)
-    assert torch.equal(neg.pixels + 100, pos.pixels)
-    assert torch.allclose(neg.features, pos.features, rtol=1e-6, atol=0)
+    m64 = ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat), num_points=n_pts)
+    m32 = ImageMapping.from_dense(T(pid), T(iid), T(pix), T(feat.astype(np.float32)), num_points=n_pts)
+    assert m64.features.dtype == torch.float64 and m32.features.dtype == torch.float32
+    assert torch.equal(m64.pointers, m32.pointers) and torch.equal(m64.pixels, m32.pixels)
+    assert torch.equal(m64.features.float(), m32.features)
+    for bad in ((pid - 5, iid, pix), (pid, iid - 1, pix), (pid, iid, pix - np.int16(3))):
+        with pytest.raises(ValueError):
+            ImageMapping.from_dense(T(bad[0]), T(bad[1]), T(bad[2]), T(feat), num_points=n_pts)
