@@ -41,7 +41,7 @@ from mvfusion.images import SameSettingImageData    # noqa: E402
 from mvfusion.pooling import segment_csr_two_level  # noqa: E402
 from mvfusion.transforms import MapImages, kdtree_order  # noqa: E402
 from mvfusion import visibility as visibility_module     # noqa: E402
-from mvfusion.distributed import gather_pooled           # noqa: E402
+from mvfusion.distributed import gather_pooled, rank_env, timed_steps   # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec peak
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, dense fp32-input MFMA (v_mfma_f32_32x32x2_f32)
@@ -295,26 +295,6 @@ def qkv_roofline(flops, fwd_ms, lanes_ms, bytes_, traffic, N, Vw, Cm):
     return out
 
 
-class Timer:
-    """Barrier + synchronize on both sides of a timed region, max over ranks."""
-
-    def __init__(self, dist, device):
-        self.dist, self.device = dist, device
-
-    def barrier(self):
-        if self.dist is not None:
-            self.dist.barrier()
-        torch.cuda.synchronize()
-
-    def elapsed(self, t0):
-        elapsed = time.perf_counter() - t0
-        if self.dist is not None:
-            t = torch.tensor([elapsed], device=self.device, dtype=torch.float64)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed
-
-
 def split_mode():
     from mvfusion import _lib
     return "bf16 MFMA 32x32x16, operands split 3-way (6 products)" if _lib.load().mvf_get_mlp_precision() \
@@ -364,8 +344,6 @@ def run_qkv(args, rank, world, device, dist, cpu_leg=True):
     torch.manual_seed(0)
     mod = pooling.QKVBimodalCSRPool(in_main=F_main, in_map=F_map, in_mod=Cm, out_mod=Cm,
                                     nc_qk=D, num_groups=G).to(device).eval()
-    tm = Timer(dist, device)
-
     # consecutive forwards are independent: they alternate between streams so
     # that the matrix-core-bound launches of one overlap the HBM-bound ones of
     # the other
@@ -385,17 +363,16 @@ def run_qkv(args, rank, world, device, dist, cpu_leg=True):
             cur.wait_stream(s)
         return out
 
-    out = forwards(args.warmup)
-    if dist is not None and out is not None:
-        # untimed: the first collective of each kind sets up its RCCL channels
-        gather_pooled(out, labels)
-    tm.barrier()
-    t0 = time.perf_counter()
-    out = forwards(args.steps)
-    if dist is not None:
-        gather_pooled(out, labels)
-    tm.barrier()
-    elapsed = tm.elapsed(t0)
+    # W untimed forwards (+ one untimed gather), then exactly K forwards + the final gather
+    # of the pooled features and labels between barrier + synchronise brackets
+    keep = {}
+
+    def finish(o):
+        keep["out"] = o
+        return gather_pooled(o, labels) if dist is not None else o
+
+    elapsed, _ = timed_steps(forwards, args.steps, args.warmup, finish, device)
+    out = keep["out"]
     if rank != 0:
         return None
     # launch duration of the whole forward with HIP events on the launch stream
@@ -497,7 +474,6 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     x_pix = torch.rand((cap, C_feat), device=device, generator=gen)
     atomic_ptr = None if splat else torch.arange(cap + 1, dtype=torch.int64, device=device)
     lib = L.load()
-    tm = Timer(dist, device)
 
     def pools(pointers, n_rows, view_ptr=None, n_pix=None):
         # pixel -> view max, then view -> point max and mean, in one pass over x_pix
@@ -592,18 +568,12 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
         return out
 
     run_steps = run_steps_single if unit == 1 else run_steps_batch
-    out = run_steps(args.warmup) if args.warmup > 0 else None
-    if dist is not None and out is not None:
-        # untimed: the first collective of each kind sets up its RCCL channels
-        gather_pooled(torch.cat(out[:2], dim=1), labels)
-    tm.barrier()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    if dist is not None:
+
+    def finish(o):
         # the path's only exchange: final gather of pooled features and labels
-        gather_pooled(torch.cat(out[:2], dim=1), labels)
-    tm.barrier()
-    elapsed = tm.elapsed(t0)
+        return gather_pooled(torch.cat(o[:2], dim=1), labels) if dist is not None else o
+
+    elapsed, _ = timed_steps(run_steps, args.steps, args.warmup, finish, device)
     if rank != 0:
         return None
 
@@ -807,9 +777,7 @@ def main():
                     help="streams that consecutive samples alternate between (1 = no overlap)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    rank, world, local = rank_env()
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)

@@ -68,6 +68,62 @@ def gather_rows(t, group=None, max_padding=1.25):
     return out, counts
 
 
+def rank_env():
+    """(rank, world size, local rank) of this process as ``torch.distributed.run`` exports
+    them (a single process without a launcher: 0, 1, 0)."""
+    import os
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)),
+            int(os.environ.get("LOCAL_RANK", 0)))
+
+
+class RankTimer:
+    """Brackets of a timed region over all ranks: barrier + device synchronisation on
+    both sides, elapsed time = MAX over the ranks."""
+
+    def __init__(self, device=None, group=None):
+        import torch.distributed as dist
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.group = group
+        self.dist = dist if dist.is_initialized() and dist.get_world_size(group) > 1 else None
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier(group=self.group)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def elapsed(self, t0):
+        import time
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+            dt = float(t.item())
+        return dt
+
+
+def timed_steps(run_steps, steps, warmup, finish=None, device=None, group=None):
+    """The timing contract of a sharded run.  ``run_steps(k)`` performs k steps of this
+    rank's share and returns what the last one produced; ``finish(out)`` is the path's
+    exchange at the end of a run (the final gather of the pooled features).  Runs
+    ``warmup`` untimed steps and one untimed ``finish`` (the first collective of a kind
+    sets up its channels), then times exactly ``steps`` steps + ``finish`` between
+    barrier + synchronise brackets.  Returns (seconds, MAX over ranks; what the timed
+    ``finish`` -- or the last step -- returned)."""
+    import time
+    out = run_steps(warmup) if warmup > 0 else None
+    if finish is not None and out is not None:
+        finish(out)
+    timer = RankTimer(device, group)
+    timer.barrier()
+    t0 = time.perf_counter()
+    out = run_steps(steps)
+    if finish is not None:
+        out = finish(out)
+    timer.barrier()
+    return timer.elapsed(t0), out
+
+
 def gather_pooled(features, labels=None, group=None):
     """The path's exchange step: pooled point features [N_r, C] (and labels
     [N_r]) of every rank, concatenated rank-major on every rank."""
@@ -124,12 +180,14 @@ def finish_view_pools(mx, sm, count):
 
 
 def combine_view_pools(mx, sm, count, group=None):
-    """The exchange step of the view-sharded layout: element-wise MAX of the
-    partial maxima and SUM of the partial sums and counts over the ranks (two
-    all-reduces: the sum and the count travel in one buffer).  Returns
-    (max pool [N, C], mean pool [N, C]) on every rank.  The max pool equals the
-    single-device pool bit for bit; the mean differs from it by float32
-    summation order only."""
+    """The exchange step of the view-sharded layout when every rank needs the
+    whole result: element-wise MAX of the partial maxima and SUM of the partial
+    sums and counts over the ranks (two all-reduces: the sum and the count travel
+    in one buffer).  Returns (max pool [N, C], mean pool [N, C]) on every rank.
+    The max pool equals the single-device pool bit for bit; the mean differs from
+    it by float32 summation order only.  Per rank a ring all-reduce sends
+    2 (w - 1) / w times the two buffers (4 N (2 C + 1) bytes): see
+    ``exchange_bytes_per_rank``."""
     import torch.distributed as dist
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         mx = mx.contiguous()
@@ -140,10 +198,67 @@ def combine_view_pools(mx, sm, count, group=None):
     return finish_view_pools(mx, sm, count)
 
 
-def view_sharded_pool(x_view, view_ptr, group=None, segment_csr=None):
+def _reduce_scatter_rows(t, op, n_own, group):
+    """Rows [world * n_own, ...] reduced over the ranks, block r to rank r.  RCCL: one
+    reduce-scatter; backends without one (gloo): all-reduce, then the own block."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    out = torch.empty((n_own,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(out, t, op=op, group=group)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+        out.copy_(t[rank * n_own:(rank + 1) * n_own])
+    return out
+
+
+def combine_view_pools_scattered(mx, sm, count, group=None):
+    """The exchange step when the consumer is point-sharded (every rank goes on with
+    its own block of points, e.g. the 3D branch of a scene split by points): two
+    reduce-scatters instead of two all-reduces, half the bytes per rank.  Points are
+    dealt in equal blocks of ceil(N / world) (the last block is short).  Returns
+    (range of owned points, max pool [n_own, C], mean pool [n_own, C])."""
+    import torch.distributed as dist
+    n = mx.shape[0]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return (range(n),) + finish_view_pools(mx, sm, count)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    block = (n + world - 1) // world
+    pad = world * block - n
+
+    def padded(t, fill):
+        if not pad:
+            return t.contiguous()
+        return torch.cat([t, t.new_full((pad,) + tuple(t.shape[1:]), fill)])
+
+    mx = _reduce_scatter_rows(padded(mx, float('-inf')), dist.ReduceOp.MAX, block, group)
+    packed = _reduce_scatter_rows(padded(torch.cat([sm, count[:, None]], dim=1), 0.0),
+                                  dist.ReduceOp.SUM, block, group)
+    own = range(rank * block, min((rank + 1) * block, n))
+    mx, mean = finish_view_pools(mx[:len(own)], packed[:len(own), :-1], packed[:len(own), -1])
+    return own, mx, mean
+
+
+def exchange_bytes_per_rank(num_points, channels, world_size, scattered=False):
+    """Bytes one rank sends in the exchange step of the view-sharded max + mean pools
+    (float32): the two buffers hold 4 N C and 4 N (C + 1) bytes; a ring all-reduce
+    sends 2 (w - 1) / w of a buffer per rank, a reduce-scatter (w - 1) / w."""
+    if world_size <= 1:
+        return 0
+    total = 4 * num_points * (2 * channels + 1)
+    factor = (world_size - 1) / world_size
+    return int(total * factor * (1 if scattered else 2))
+
+
+def view_sharded_pool(x_view, view_ptr, group=None, segment_csr=None, scattered=False):
     """View -> point max and mean pools of a scene whose views are sharded over
-    the ranks: local pre-reduction + ``combine_view_pools``."""
-    return combine_view_pools(*local_view_pools(x_view, view_ptr, segment_csr), group=group)
+    the ranks: local pre-reduction + ``combine_view_pools`` (every rank gets all
+    points) or, ``scattered``, ``combine_view_pools_scattered`` (every rank gets its
+    block of points: returns (owned range, max, mean))."""
+    parts = local_view_pools(x_view, view_ptr, segment_csr)
+    if scattered:
+        return combine_view_pools_scattered(*parts, group=group)
+    return combine_view_pools(*parts, group=group)
 
 
 # --------------------------------------------------------------------------- #

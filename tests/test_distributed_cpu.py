@@ -122,7 +122,10 @@ def _view_worker(rank, world, port, q):
         views = D.partition_views(sees.shape[1])
         x, ptr = _local_csr(sees, feats, views)
         mx, mean = D.view_sharded_pool(x, ptr, segment_csr=_np_segment_csr)
-        q.put((rank, list(views), mx.numpy(), mean.numpy()))
+        # the point-sharded consumer: every rank keeps its block of points only
+        own, mx_own, mean_own = D.view_sharded_pool(x, ptr, segment_csr=_np_segment_csr, scattered=True)
+        assert torch.equal(mx_own, mx[own.start:own.stop]) and torch.equal(mean_own, mean[own.start:own.stop])
+        q.put((rank, list(views), mx.numpy(), mean.numpy(), [own.start, own.stop]))
     finally:
         dist.destroy_process_group()
 
@@ -157,6 +160,71 @@ def test_view_sharded_pool_world2_gloo():
         np.testing.assert_allclose(r[3], want_mean, rtol=1e-5, atol=1e-6)
     assert np.array_equal(res[0][3], res[1][3])
     assert (want_max[25:] < 0).any() and not want_max[:25].any()
+    assert res[0][4] == [0, 250] and res[1][4] == [250, 500]
+    # bytes a rank sends in the exchange: reduce-scatter moves half of what all-reduce does
+    assert D.exchange_bytes_per_rank(2_000_000, 64, 8) == 2 * D.exchange_bytes_per_rank(2_000_000, 64, 8, True)
+    assert D.exchange_bytes_per_rank(2_000_000, 64, 8, True) == int(4 * 2_000_000 * 129 * 7 / 8)
+    assert D.exchange_bytes_per_rank(10, 4, 1) == 0
+
+
+def test_combine_view_pools_scattered_single_process_and_uneven_blocks():
+    sees, feats = _view_scene()
+    x, ptr = _local_csr(sees, feats, range(12))
+    parts = D.local_view_pools(x, ptr, _np_segment_csr)
+    own, mx, mean = D.combine_view_pools_scattered(*parts)
+    want = D.combine_view_pools(*parts)
+    assert own == range(500) and torch.equal(mx, want[0]) and torch.equal(mean, want[1])
+
+
+# ------------------------------------------------------------ timing harness
+def _timed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        assert D.rank_env() == (rank, world, rank)
+        calls = []
+        n_rows = 5 + 3 * rank
+
+        def run_steps(k):
+            calls.append(k)
+            time.sleep(0.02 * k * (1 + 2 * rank))             # rank 1 is three times slower
+            return torch.full((n_rows, 2), float(rank)), torch.full((n_rows,), rank, dtype=torch.int64)
+
+        seconds, (f, l, counts) = D.timed_steps(
+            run_steps, steps=4, warmup=2, finish=lambda out: D.gather_pooled(out[0], out[1]))
+        q.put((rank, calls, seconds, f.numpy(), l.numpy(), counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_timed_steps_world2_gloo():
+    """The function bench.py times its steps with: warm-up steps and one untimed exchange,
+    then exactly K steps + the final gather between barriers, the slowest rank's time on
+    every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_timed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[1] == [2, 4]                                  # warm-up, then exactly K steps
+        assert r[5] == [5, 8] and r[3].shape == (13, 2)
+        assert np.array_equal(r[4], np.array([0] * 5 + [1] * 8))
+    assert res[0][2] == res[1][2] >= 0.02 * 4 * 3              # MAX over ranks, the same on both
+
+
+def test_timed_steps_single_process():
+    seen = []
+    seconds, out = D.timed_steps(lambda k: seen.append(k) or k, steps=3, warmup=0)
+    assert seen == [3] and out == 3 and seconds >= 0.0
 
 
 # ------------------------------------------------- view rows to point owners
