@@ -615,17 +615,18 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
     D = design_bytes(N, V, M, Pn, plan.F, C_feat, m_fov, pairs, depth=depth, splat=splat)
     S_ = survey_model_bytes(N, V, W, H, Pn, plan.F, C_feat, depth=depth, m_fov=m_fov, Vw=M)
     ms_step = elapsed / args.steps * 1e3
+    tcfg = cfg if (exact or depth) else cfg + "_nonexact"      # key of the PMC traffic table
 
     def hbm(stage):
         """Design bytes and PMC-measured bytes of one launch of a stage against the HBM peak."""
         t = stages[stage] * 1e-3
-        traffic = pmc_traffic(cfg, stage)
+        traffic = pmc_traffic(tcfg, stage)
         return dict(design_bytes_per_launch=D[stage] * per, frac=D[stage] * per / t / HBM_PEAK,
                     traffic=traffic, measured_frac=None if traffic is None else traffic / t / HBM_PEAK)
 
     per_stage = {k: dict(hbm(k), kernel_ms=round(stages[k], 4)) for k in D if k in stages}
     dom = max(per_stage, key=lambda k: stages[k])
-    step_traffic = pmc_traffic(cfg, "step")
+    step_traffic = pmc_traffic(tcfg, "step")
     pipeline = dict(
         design_bytes_per_step=D["total"] * n_samples, survey_model_bytes_per_step=S_["total"] * n_samples,
         ms_per_step=ms_step, achieved=D["total"] * n_samples / (ms_step * 1e-3) / 1e9,
@@ -796,13 +797,18 @@ def main():
         # short runs of the other workloads, so that one invocation records them all
         line["end_to_end"] = end_to_end("c2", device)
         others = {}
-        for name in ("c1", "c3", "c4", "c5"):
+        for name in ("c1", "c2_nonexact", "c3", "c4", "c5"):
             torch.cuda.empty_cache()
             short = argparse.Namespace(**vars(args))
-            short.steps = 30 if name == "c3" else 100
+            short.steps = 30 if name in ("c3", "c2_nonexact") else 100
             short.warmup = 5
             if name == "c3":
                 r = run_qkv(short, 0, 1, device, None, cpu_leg=False)
+            elif name == "c2_nonexact":
+                # config 2 as BASELINE words it: plain splat visibility (exact=False), every
+                # pixel a point wins is a mapping
+                short.exact = 0
+                r = run_map_pool("c2", short, 0, 1, device, None, cpu_leg=False)
             else:
                 r = run_map_pool(name, short, 0, 1, device, None, cpu_leg=False)
             rf = r["roofline"]
@@ -814,6 +820,7 @@ def main():
                                 points_per_gpu=r["config"].get("points_per_gpu"),
                                 views=r["config"].get("views"),
                                 mappings_per_sample=r["config"].get("mappings_per_sample"),
+                                pixels_per_sample=r["config"].get("pixels_per_sample"),
                                 roofline={k: rf[k] for k in keep if k in rf})
             if "training_step" in r:
                 others[name]["training_step"] = r["training_step"]

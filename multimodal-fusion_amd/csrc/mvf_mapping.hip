@@ -608,6 +608,9 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
 {
     __shared__ __align__(16) u64 zb[ZB_KEYS];
     __shared__ unsigned s_next;
+#ifdef MVF_ZB_PRIO
+    __builtin_amdgcn_s_setprio(MVF_ZB_PRIO);
+#endif
     const unsigned nd = *n_desc;
     if (blockIdx.x >= nd) return;
 #ifdef MVF_ZB_DEBUG
