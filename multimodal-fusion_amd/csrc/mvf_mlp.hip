@@ -497,6 +497,86 @@ __device__ __forceinline__ void mlp_pool_tail_scan(
     }
 }
 
+// The segment maximum (POOL 3) as a segmented inclusive scan over the lanes, like the sums of
+// mlp_pool_tail_scan: in steps of 1, 2, 4, 8 lanes inside a DPP row and one step into the
+// second row, every lane takes the maximum of its value and that of the lane `shift` behind,
+// where its segment reaches that far back.  Per register and step: v_add_f32 with a DPP
+// source and the lane's bias (0 where the step applies, -inf where it does not: the sum is
+// then -inf and loses; a lane without a source reads 0, or keeps a preset -inf) and v_max_f32.  No
+// branch and no exec masking: every lane stays a valid DPP source.  A maximum does not
+// depend on the order of its operands, so the result has the bits of the in-order fold.
+// The last row of a segment stores its channels with 16-byte stores; a segment that
+// continues in a neighbouring tile meets its other parts in a row preset to -inf
+// (segmax_prepare_kernel) through atomic maxima.  Needs cout % 4 == 0 and a 16-byte
+// aligned output.
+__device__ __forceinline__ void mlp_pool_tail_scanmax(
+    const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout,
+    int pseg, int pprev, int pnext, int lane)
+{
+    const int jrow = lane & 31, kh = lane >> 5;
+    const int behind = __shfl_up(pseg, 1, 64);
+    const bool is_start = jrow == 0 || pseg != behind;
+    const unsigned starts = (unsigned)__ballot(is_start);            // lanes 0 .. 31
+    const int first = 31 - __clz((int)(starts & (0xffffffffu >> (31 - jrow))));
+    const int d = jrow - first;                                      // rows of the segment behind this one
+    const int dd = d < (jrow & 15) ? d : (jrow & 15);                // ... inside the DPP row of 16 lanes
+    const bool is_end = jrow == 31 || ((starts >> (jrow + 1)) & 1u);
+    // PRESET_: the step leaves some lanes unwritten (row_mask), so the sum starts from -inf;
+    // the row_shr steps read 0 for a lane without a source (bound_ctrl), whose bias is -inf.
+#define MVF_SCANMAX_STEP(COND_, DPP_, PRESET_)                                                    \
+    {                                                                                             \
+        const float b_ = (COND_) ? 0.f : -INFINITY;                                               \
+        asm volatile("s_nop 1" ::: "memory");                                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                          \
+            float t_, u_;                                                                         \
+            if (PRESET_) {                                                                        \
+                t_ = -INFINITY;                                                                   \
+                asm volatile("v_add_f32_dpp %0, %1, %2 " DPP_ : "+v"(t_) : "v"(acc0[r]), "v"(b_)); \
+            } else {                                                                              \
+                asm volatile("v_add_f32_dpp %0, %1, %2 " DPP_ : "=v"(t_) : "v"(acc0[r]), "v"(b_)); \
+            }                                                                                     \
+            asm volatile("v_max_f32 %0, %1, %0" : "+v"(acc0[r]) : "v"(t_));                       \
+            if (wide) {                                                                           \
+                if (PRESET_) {                                                                    \
+                    u_ = -INFINITY;                                                               \
+                    asm volatile("v_add_f32_dpp %0, %1, %2 " DPP_ : "+v"(u_) : "v"(acc1[r]), "v"(b_)); \
+                } else {                                                                          \
+                    asm volatile("v_add_f32_dpp %0, %1, %2 " DPP_ : "=v"(u_) : "v"(acc1[r]), "v"(b_)); \
+                }                                                                                 \
+                asm volatile("v_max_f32 %0, %1, %0" : "+v"(acc1[r]) : "v"(u_));                   \
+            }                                                                                     \
+        }                                                                                         \
+    }
+    MVF_SCANMAX_STEP(dd >= 1, "row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", false)
+    MVF_SCANMAX_STEP(dd >= 2, "row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1", false)
+    MVF_SCANMAX_STEP(dd >= 4, "row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", false)
+    MVF_SCANMAX_STEP(dd >= 8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", false)
+    MVF_SCANMAX_STEP((jrow & 16) && d > (jrow & 15), "row_bcast:15 row_mask:0xa bank_mask:0xf", true)
+#undef MVF_SCANMAX_STEP
+    if (!(is_end && pseg >= 0)) return;
+    // the segment began before the tile (it holds the tile's first row and the row in front
+    // of the tile) or goes on behind it
+    const bool partial = (d == jrow && pseg == pprev) || (jrow == 31 && pseg == pnext);
+    float *o = A.pool_out + (size_t)pseg * cout + 4 * kh;
+    if (!partial) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (8 * g + 4 * kh < cout)
+                *(float4 *)(o + 8 * g) = make_float4(acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+            if (wide && 32 + 8 * g + 4 * kh < cout)
+                *(float4 *)(o + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (8 * g + 4 * kh < cout) atomic_max_float(o + 8 * g + e, acc0[4 * g + e]);
+                if (wide && 32 + 8 * g + 4 * kh < cout) atomic_max_float(o + 32 + 8 * g + e, acc1[4 * g + e]);
+            }
+    }
+}
+
 // NL / WMASK >= 0 fix the number of layers and which of them are wider than 32
 // outputs (bit l of WMASK) at compile time, for the aligned single-source or
 // concatenated inputs (mode 0, 16-byte loads and stores): layer loops unroll
@@ -873,6 +953,12 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             }
         }
     pool_tail:
+#ifndef MVF_SEGMAX_FOLD
+        if (POOL == 3)
+            mlp_pool_tail_scanmax(A, acc0, acc1, cop_of(nlayers - 1) > 32, A.L[nlayers - 1].cout,
+                                  pseg, pprev, pnext, lane);
+        else
+#endif
         if (POOL)
             mlp_pool_tail<POOL>(A, acc0, acc1, cop_of(nlayers - 1) > 32, A.L[nlayers - 1].cout,
                                 smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH),
@@ -1253,8 +1339,12 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
             mlp_pool_tail_scan<POOL == 2 ? 2 : 1>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                                                   pseg, pprev, pnext, patt, lane, base + wave * 32);
         else if (POOL == 3)
+#ifndef MVF_SEGMAX_FOLD
+            mlp_pool_tail_scanmax(A, n0, n1, true, L1.cout, pseg, pprev, pnext, lane);
+#else
             mlp_pool_tail<3>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                              pseg, pprev, pnext, patt, lane, base + wave * 32);
+#endif
 #pragma unroll
         for (int t = 8; t < 8 * NQ0; ++t) xr[t] = xn[t];
         STAMP(2)
