@@ -497,6 +497,8 @@ __device__ __forceinline__ void mlp_pool_tail_scan(
     }
 }
 
+// (Built with -DMVF_SEGMAX_SCAN only: measured on 2 M rows, 8 -> 32 -> 32, the launch takes 138 us
+// with this scan and 135 us with the LDS fold of mlp_pool_tail<3>, which stays the default.)
 // The segment maximum (POOL 3) as a segmented inclusive scan over the lanes, like the sums of
 // mlp_pool_tail_scan: in steps of 1, 2, 4, 8 lanes inside a DPP row and one step into the
 // second row, every lane takes the maximum of its value and that of the lane `shift` behind,
@@ -507,10 +509,10 @@ __device__ __forceinline__ void mlp_pool_tail_scan(
 // depend on the order of its operands, so the result has the bits of the in-order fold.
 // The last row of a segment stores its channels with 16-byte stores; a segment that
 // continues in a neighbouring tile meets its other parts in a row preset to -inf
-// (segmax_prepare_kernel) through atomic maxima.  Needs cout % 4 == 0 and a 16-byte
-// aligned output.
+// (segmax_prepare_kernel) through atomic maxima, issued from two staging rows (`stage2`) so
+// that one instruction takes 64 channels.  Needs cout % 4 == 0 and a 16-byte aligned output.
 __device__ __forceinline__ void mlp_pool_tail_scanmax(
-    const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout,
+    const MlpArgs &A, floatx16 &acc0, floatx16 &acc1, bool wide, int cout, float *stage2,
     int pseg, int pprev, int pnext, int lane)
 {
     const int jrow = lane & 31, kh = lane >> 5;
@@ -553,12 +555,15 @@ __device__ __forceinline__ void mlp_pool_tail_scanmax(
     MVF_SCANMAX_STEP(dd >= 8, "row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", false)
     MVF_SCANMAX_STEP((jrow & 16) && d > (jrow & 15), "row_bcast:15 row_mask:0xa bank_mask:0xf", true)
 #undef MVF_SCANMAX_STEP
-    if (!(is_end && pseg >= 0)) return;
-    // the segment began before the tile (it holds the tile's first row and the row in front
-    // of the tile) or goes on behind it
-    const bool partial = (d == jrow && pseg == pprev) || (jrow == 31 && pseg == pnext);
-    float *o = A.pool_out + (size_t)pseg * cout + 4 * kh;
-    if (!partial) {
+    // Segments that continue in a neighbouring tile (at most the first and the last one, known
+    // wave-wide) go through two staging rows so that one atomic instruction takes 64 channels.
+    const int seg0 = __builtin_amdgcn_readlane(pseg, 0), seg31 = __builtin_amdgcn_readlane(pseg, 31);
+    const bool part1 = seg31 >= 0 && seg31 == pnext;
+    const bool part0 = seg0 >= 0 && seg0 == pprev && !(part1 && seg0 == seg31);
+    const bool mine_partial = (part0 && pseg == seg0) || (part1 && pseg == seg31);
+    if (is_end && pseg >= 0) {
+        float *o = mine_partial ? stage2 + (pseg == seg31 && part1 ? POOL_PITCH : 0) + 4 * kh
+                                : A.pool_out + (size_t)pseg * cout + 4 * kh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (8 * g + 4 * kh < cout)
@@ -566,14 +571,16 @@ __device__ __forceinline__ void mlp_pool_tail_scanmax(
             if (wide && 32 + 8 * g + 4 * kh < cout)
                 *(float4 *)(o + 32 + 8 * g) = make_float4(acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
         }
-    } else {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (8 * g + 4 * kh < cout) atomic_max_float(o + 8 * g + e, acc0[4 * g + e]);
-                if (wide && 32 + 8 * g + 4 * kh < cout) atomic_max_float(o + 32 + 8 * g + e, acc1[4 * g + e]);
-            }
+    }
+    if (part0 || part1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (part0 && lane < cout) atomic_max_float(A.pool_out + (size_t)seg0 * cout + lane, stage2[lane]);
+        if (part1 && lane < cout) atomic_max_float(A.pool_out + (size_t)seg31 * cout + lane, stage2[POOL_PITCH + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -953,9 +960,10 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             }
         }
     pool_tail:
-#ifndef MVF_SEGMAX_FOLD
+#ifdef MVF_SEGMAX_SCAN
         if (POOL == 3)
             mlp_pool_tail_scanmax(A, acc0, acc1, cop_of(nlayers - 1) > 32, A.L[nlayers - 1].cout,
+                                  smem + stage_off + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                                   pseg, pprev, pnext, lane);
         else
 #endif
@@ -1339,8 +1347,9 @@ void mlp_wide2_bf3_kernel(MlpArgs A)
             mlp_pool_tail_scan<POOL == 2 ? 2 : 1>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                                                   pseg, pprev, pnext, patt, lane, base + wave * 32);
         else if (POOL == 3)
-#ifndef MVF_SEGMAX_FOLD
-            mlp_pool_tail_scanmax(A, n0, n1, true, L1.cout, pseg, pprev, pnext, lane);
+#ifdef MVF_SEGMAX_SCAN
+            mlp_pool_tail_scanmax(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
+                                  pseg, pprev, pnext, lane);
 #else
             mlp_pool_tail<3>(A, n0, n1, true, L1.cout, stage + wave * (POOL_STAGE_ROWS * POOL_PITCH),
                              pseg, pprev, pnext, patt, lane, base + wave * 32);
@@ -2176,22 +2185,25 @@ extern "C" int mvf_mlp_forward_dot(
 
 // Sums of the segments that cross a tile boundary, from the per-tile partial sums the pool
 // epilogue left (MlpArgs::pool_part), added in tile order: the first tile's slot 1, the slots
-// 1 of the tiles that lie inside the segment, the last tile's slot 0.  One thread per
-// (segment, 4 channels); segments inside one tile were stored by the epilogue.
+// 1 of the tiles that lie inside the segment, the last tile's slot 0.  One thread per (tile,
+// 4 channels): it completes the segment that begins in its tile and continues behind it, if
+// there is one.  Segments inside one tile were stored by the epilogue.
 __global__ __launch_bounds__(256) void pool_fixup_kernel(
-    const i64 *__restrict__ ptr, i64 nseg, int cout, const float *__restrict__ part, float *__restrict__ out)
+    const i64 *__restrict__ ptr, const int *__restrict__ row2seg, i64 rows, unsigned tiles, unsigned q,
+    const float *__restrict__ part, float *__restrict__ out)
 {
-    const int q = cout >> 2;
-    const i64 t = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (t >= nseg * q) return;
-    const i64 s = t / q;
-    const int c = (int)(t - s * q) * 4;
-    const i64 a = ptr[s], b = ptr[s + 1];
-    if (b <= a) return;
-    const i64 ta = a / POOL_TILE, tb = (b - 1) / POOL_TILE;
-    if (ta == tb) return;
-    float4 acc = *(const float4 *)(part + ((size_t)ta * 2 + 1) * cout + c);
-    for (i64 u = ta + 1; u <= tb; ++u) {
+    const unsigned t = blockIdx.x * 256u + threadIdx.x;
+    const unsigned tile = t / q;
+    if (tile >= tiles) return;
+    const unsigned cout = 4u * q, c = (t - tile * q) * 4u;
+    const i64 first = (i64)tile * POOL_TILE, next = first + POOL_TILE;
+    if (next >= rows) return;                          // the last tile: nothing continues behind it
+    const int s = row2seg[next - 1];
+    const i64 b = ptr[s + 1];
+    if (b <= next || ptr[s] < first) return;           // ends here, or began in an earlier tile
+    const i64 tb = (b - 1) / POOL_TILE;
+    float4 acc = *(const float4 *)(part + ((size_t)tile * 2 + 1) * cout + c);
+    for (i64 u = (i64)tile + 1; u <= tb; ++u) {
         const float4 v = *(const float4 *)(part + ((size_t)u * 2 + (u == tb ? 0 : 1)) * cout + c);
         acc.x = __fadd_rn(acc.x, v.x); acc.y = __fadd_rn(acc.y, v.y);
         acc.z = __fadd_rn(acc.z, v.z); acc.w = __fadd_rn(acc.w, v.w);
@@ -2225,8 +2237,11 @@ extern "C" int mvf_mlp_forward_pool(
                                   nlayers, nullptr, 0, nullptr, 0, row2seg, 0.f, nullptr, stream, att, pool_out, G,
                                   false, (float *)workspace))
         return rc;
-    hipLaunchKernelGGL(pool_fixup_kernel, dim3(cdiv(nseg * (cout / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const i64 *)ptr, (i64)nseg, cout, (const float *)workspace, pool_out);
+    const i64 tiles = (rows + POOL_TILE - 1) / POOL_TILE;
+    MVF_REQUIRE(tiles * (cout / 4) < (1ll << 32), "mlp_forward_pool: too many rows");
+    hipLaunchKernelGGL(pool_fixup_kernel, dim3(cdiv(tiles * (cout / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const i64 *)ptr, row2seg, (i64)rows, (unsigned)tiles, (unsigned)(cout / 4),
+                       (const float *)workspace, pool_out);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
 }
