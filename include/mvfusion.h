@@ -115,7 +115,14 @@ int mvf_camera_projection(
  * mvf_camera_projection_noalloc_max_points() = 2^24 points; a larger n is
  * rejected with MVF_E_INVALID.  The call allocates and frees nothing.  All
  * calls on one GPU share that array: calls that overlap on one GPU (different
- * streams or threads) race; serialise them. */
+ * streams or threads) race; serialise them.
+ * The array's device address is looked up once per GPU (a symbol query that
+ * may load the code object, and is no stream operation): that has to happen
+ * OUTSIDE a graph capture.  mvf_camera_projection_noalloc_max_points() does
+ * the look-up for the current device, so calling it once per GPU at set-up
+ * makes every later mvf_camera_projection_noalloc call on that GPU capture-
+ * safe (a first compute call outside capture does the same).  `stream` must
+ * belong to the device that is current at the call. */
 int64_t mvf_camera_projection_noalloc_max_points(void);
 int mvf_camera_projection_noalloc(
     const float *xyz, int64_t n, const mvf_view *h_view,

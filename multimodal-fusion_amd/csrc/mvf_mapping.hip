@@ -1692,7 +1692,14 @@ static unsigned *scratch_on_current_device()
     return g_scratch_ptr[dev];
 }
 
-extern "C" int64_t mvf_camera_projection_noalloc_max_points(void) { return NOALLOC_MAX_POINTS; }
+extern "C" int64_t mvf_camera_projection_noalloc_max_points(void)
+{
+    // also the set-up call: resolves the scratch array's address on the current device (when
+    // there is one), so that no later call has to do it under a graph capture
+    int count = 0;
+    if (hipGetDeviceCount(&count) == hipSuccess && count > 0) (void)scratch_on_current_device();
+    return NOALLOC_MAX_POINTS;
+}
 
 extern "C" int mvf_camera_projection_noalloc(
     const float *xyz, int64_t n, const mvf_view *h_view, const mvf_vis_params *h_params,

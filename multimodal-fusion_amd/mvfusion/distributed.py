@@ -36,8 +36,11 @@ def gather_rows(t, group=None, max_padding=1.25):
     rank r -> [sum n_r, ...] on every rank, rank-major.  One small all-gather
     of the counts, then the payload: one all-gather of blocks padded to the
     longest when that moves at most ``max_padding`` times the rows there are
-    (balanced shards), otherwise one broadcast per rank straight into its slice
-    of the result, so that an uneven partition does not travel as padding."""
+    (balanced shards); otherwise every rank sends its block straight to every
+    peer and receives the peers' blocks into their slices of the result, all in
+    one batch of point-to-point operations -- on a fully connected xGMI node each
+    pair has its own link, so an uneven partition neither travels as padding nor
+    waits for one rank after the other."""
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return t, [t.shape[0]]
@@ -56,15 +59,23 @@ def gather_rows(t, group=None, max_padding=1.25):
         out = out.view((world, cap) + tail)
         return torch.cat([out[r, :counts[r]] for r in range(world)], dim=0), counts
     out = torch.empty((total,) + tail, dtype=t.dtype, device=t.device)
-    me, start = dist.get_rank(group), 0
+    me = dist.get_rank(group)
+    t = t.contiguous()
+    ops, start = [], 0
     for r in range(world):
         block = out[start:start + counts[r]]
+        start += counts[r]
         if r == me:
             block.copy_(t)
+            continue
+        peer = dist.get_global_rank(group, r) if group is not None else r
+        if counts[me]:
+            ops.append(dist.P2POp(dist.isend, t, peer, group=group))
         if counts[r]:
-            dist.broadcast(block, src=dist.get_global_rank(group, r) if group is not None else r,
-                           group=group)
-        start += counts[r]
+            ops.append(dist.P2POp(dist.irecv, block, peer, group=group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return out, counts
 
 

@@ -24,6 +24,7 @@ needs no host work; a precomputed permutation may be supplied as
 ``data.mvf_point_order``.
 """
 import ctypes as C
+import threading
 import time
 
 import numpy as np
@@ -77,22 +78,62 @@ _NO_MAPPING_MSG = (
     "transformation.")
 
 
-def kdtree_order(pos, cylinder, threads=0):
+_PINNED = threading.local()
+
+
+def _pinned(tag, shape, dtype):
+    """A page-locked host buffer kept for the life of the process (one per purpose and
+    size): freshly allocated host memory costs a page fault per 4 KB on first touch --
+    several milliseconds for a few megabytes in a process that has mapped a GPU -- and
+    page-locked memory also copies to and from the device at full rate.  The event is
+    recorded after the last device copy out of the buffer: wait for it before writing."""
+    cache = _PINNED.__dict__.setdefault('buffers', {})       # one set per calling thread
+    key = (tag, tuple(shape), dtype)
+    hit = cache.get(key)
+    if hit is None:
+        if len(cache) > 16:
+            cache.clear()
+        hit = cache[key] = [torch.empty(shape, dtype=dtype).pin_memory(), None]
+    if hit[1] is not None:
+        hit[1].synchronize()
+        hit[1] = None
+    return hit
+
+
+def kdtree_order(pos, cylinder, threads=0, device=None):
     """Traversal order of the KD-tree the reference's radius samplers build
     (transforms.py:326,380): ``query_radius`` returns the points of that order
     that fall inside the radius.  Computed by the library's own host routine
     (``mvf_kdtree_order``: the same permutation as
-    ``sklearn.neighbors.KDTree(leaf_size=50).idx_array``, without sklearn)."""
+    ``sklearn.neighbors.KDTree(leaf_size=50).idx_array``, without sklearn).
+    ``device``: return the order as a tensor on that HIP device (staged through
+    page-locked buffers, nothing allocated on the host per call); otherwise a host
+    tensor."""
     p = pos.detach()
-    if p.is_cuda:
-        p = p.cpu()
-    p = np.ascontiguousarray(np.asarray(p, dtype=np.float32))
     n = p.shape[0]
-    order = np.empty(n, dtype=np.int64)
-    if n:
-        L.check(L.load().mvf_kdtree_order(
-            p.ctypes.data, n, 2 if cylinder else 3, p.shape[1], 50, order.ctypes.data, int(threads)))
-    return torch.from_numpy(order)
+    staged = device is not None and torch.device(device).type == 'cuda'
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=device if staged else None)
+    if p.is_cuda:
+        # through a page-locked buffer (a pageable copy allocates and faults in fresh memory)
+        buf = _pinned('kd_pos', p.shape, torch.float32)[0]
+        buf.copy_(p.to(torch.float32), non_blocking=True)
+        torch.cuda.current_stream(p.device).synchronize()
+        p = buf
+    p = np.ascontiguousarray(np.asarray(p, dtype=np.float32))
+    if staged:
+        slot = _pinned('kd_order', (n,), torch.int64)
+        order = np.asarray(slot[0])
+    else:
+        order = np.empty(n, dtype=np.int64)
+    L.check(L.load().mvf_kdtree_order(
+        p.ctypes.data, n, 2 if cylinder else 3, p.shape[1], 50, order.ctypes.data, int(threads)))
+    if not staged:
+        return torch.from_numpy(order)
+    out = slot[0].to(device, non_blocking=True)
+    slot[1] = torch.cuda.Event()
+    slot[1].record(torch.cuda.current_stream(device))
+    return out
 
 
 def _source_key(tag, tensors):
@@ -469,16 +510,17 @@ class MapImages(ImageTransform):
         self.timings = {}
 
     # ------------------------------------------------------------------ #
-    def _order(self, data):
+    def _order(self, data, device=None):
         """Local point order of the sample; the KD-tree order is kept on
         ``data`` for the next call, as the reference keeps the tree itself
-        (transforms.py:325-329,379-383)."""
+        (transforms.py:325-329,379-383).  ``device``: where a newly built order
+        is wanted."""
         order = getattr(data, ORDER_KEY, None)
         if order is not None and order.shape[0] == data.pos.shape[0]:
             return order
         if self.point_order == 'index':
             return None
-        order = kdtree_order(data.pos, self.cylinder)
+        order = kdtree_order(data.pos, self.cylinder, device=device)
         try:
             setattr(data, ORDER_KEY, order)
         except Exception:
@@ -765,7 +807,7 @@ class MapImages(ImageTransform):
         depth = self.method == 'DepthBasedVisibility'
         t0 = time.perf_counter()
         # the depth test has no ties: any point order gives the same mappings
-        order = None if depth else self._order(data)
+        order = None if depth else self._order(data, device)
         self.timings['t_sphere_sampling'] = (time.perf_counter() - t0) * 1e3
         staged = self._stage_points(data, order, device)
         if staged is None:
