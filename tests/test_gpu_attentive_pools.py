@@ -532,3 +532,45 @@ def test_unaligned_input_rows_take_the_aligned_kernels(cin, widths, offset):
     ref = dense.run_layers(dense.mlp_layers(enc.mlp_elt_2), torch.cat([x1, gather_csr(x_set, ptr)], 1))
     scale = float(ref.abs().max())
     assert float((out - ref).abs().max()) < 1e-5 * scale
+
+
+def test_non_finite_view_row_stays_in_its_point_or_tile():
+    """One view row of NaN features.  The reference's segment sum keeps it to the point that
+    owns the row.  So do the float32 chains (mvf_set_mlp_precision(0)) and the unfused
+    launches (save_last); the split-bf16 value encoder sums a tile of 32 rows with a masked
+    scan, where 0 x NaN reaches the other points of that tile -- and no point beyond it."""
+    from mvfusion import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    N, C = 4000, 64
+    counts = np.full(N, 3)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    Vw = int(ptr[-1])
+    x_main = rng.random((N, 32)).astype(np.float32)
+    x_mod = rng.random((Vw, C)).astype(np.float32)
+    x_map = rng.random((Vw, 8)).astype(np.float32)
+    bad_point = 1500
+    bad_row = int(ptr[bad_point]) + 1
+    x_mod[bad_row] = np.nan
+    tile = bad_row // 32
+    in_tile = np.nonzero((ptr[:-1] < (tile + 1) * 32) & (ptr[1:] > tile * 32))[0]
+    assert bad_point in in_tile and 8 <= len(in_tile) <= 12
+    torch.manual_seed(4)
+    mod = _random_module(pooling.QKVBimodalCSRPool(
+        in_main=32, in_map=8, in_mod=C, out_mod=C, num_groups=1, nc_qk=16, gating=False), 5).to(DEV).eval()
+    args = (T(x_main), T(x_mod), T(x_map), T(ptr))
+    before = lib.mvf_get_mlp_precision()
+    try:
+        for precision, save_last in ((0, False), (1, True), (1, False)):
+            lib.mvf_set_mlp_precision(precision)
+            mod.save_last = save_last
+            out = mod(*args).cpu().numpy()
+            hit = np.nonzero(~np.isfinite(out).all(axis=1))[0]
+            assert bad_point in hit
+            if precision == 0 or save_last:
+                assert list(hit) == [bad_point], (precision, save_last, hit)
+            else:
+                assert set(hit) <= set(in_tile), (hit, in_tile)
+    finally:
+        lib.mvf_set_mlp_precision(before)
+        mod.save_last = False
