@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void two_level_pool_kernel(
     const unsigned cv = (unsigned)(C / VEC);
     const i64 e = (i64)blockIdx.x * 256 + threadIdx.x;
     if (e >= n_outer * cv) return;
-    const i64 seg = e / cv;
+    // (a 32-bit division where the index allows it: the 64-bit one is a hundred instructions)
+    const i64 seg = n_outer * cv <= 0xffffffffll ? (i64)((unsigned)e / cv) : e / cv;
     const V *s = (const V *)src + (unsigned)(e - seg * cv);
     const i64 va = outer_ptr[seg], vb = outer_ptr[seg + 1];
     V sum, mn, mx;

@@ -15,6 +15,8 @@ from mvfusion.pooling import segment_csr_two_level  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+# "nocopy": the captured graph holds kernels (and the call's memset) only, no copy of the sizes
+NOCOPY = len(sys.argv) > 3 and sys.argv[3] == "nocopy"
 dev = torch.device("cuda", 0)
 wl = B.WORKLOADS[cfg]
 C_feat = wl["channels"]
@@ -69,7 +71,8 @@ for lanes in (1, 3):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             p.launch(0)
-            sl[2].copy_(sl[1], non_blocking=True)
+            if not NOCOPY:
+                sl[2].copy_(sl[1], non_blocking=True)
             outs.append(pools(sl[4]))
         graphs.append(g)
         events.append(torch.cuda.Event())
@@ -83,7 +86,7 @@ for lanes in (1, 3):
         for j in range(k):
             ln = j % lanes
             events[ln].synchronize()
-            assert hosts[ln][2].item() == 0          # no overflow
+            assert NOCOPY or hosts[ln][2].item() == 0          # no overflow
             if j + lanes < k:
                 with torch.cuda.stream(streams[ln]):
                     graphs[ln].replay()
