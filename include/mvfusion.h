@@ -277,19 +277,27 @@ int mvf_map_images_exact_batch(
  * room for out_capacity views; pixels (int16 [P][2], ascending (x, y) inside a
  * view: the reference's order inside a view is unspecified) with room for
  * pix_capacity; features [Vw][F] = mean over the view's pixels.
+ * mask_capacity: room of the pass's verdict buffer, in entries of 8 pixels:
+ * every (point, view) pair that wins a pixel takes one entry per column of
+ * its splat box and group of 8 image rows (8g .. 8g+7) the box reaches
+ * (0 = a quarter of an entry per pixel of the views; the workspace size
+ * follows it, so pass the same value to both functions).
  * counters (8 words): [0] <- Vw, [1] <- (splat, tile) pairs needed,
  * [2] <- overflow flags (bit 0: pair_capacity or out_capacity, bit 2:
- * pix_capacity), [3] <- views with at least one mapping, [4] <- P.
+ * pix_capacity, bit 3: mask_capacity), [3] <- views with at least one
+ * mapping, [4] <- P, [5] <- verdict entries needed.  After an overflow the
+ * outputs are incomplete: call again with the capacities the counters name.
  * ---------------------------------------------------------------------- */
 size_t mvf_map_images_splat_workspace_bytes(
-    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity);
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity,
+    int64_t mask_capacity);
 int mvf_map_images_splat(
     const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points,
     const mvf_view *views, int32_t V, const mvf_vis_params *h_params,
     int32_t cylinder, const uint8_t *mask, const float *linearity,
     const float *planarity, const float *scattering, const float *normals,
-    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers,
-    int64_t *images, int64_t *view_pointers, int16_t *pixels, float *features,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t mask_capacity,
+    int64_t *pointers, int64_t *images, int64_t *view_pointers, int16_t *pixels, float *features,
     int64_t out_capacity, int64_t pix_capacity, int32_t *view_seen,
     int64_t *counters, void *workspace, size_t workspace_bytes, void *stream);
 

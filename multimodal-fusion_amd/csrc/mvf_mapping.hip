@@ -739,9 +739,15 @@ __global__ __launch_bounds__(ZB_THREADS) void tile_zbuffer_kernel(
                 const int gx = x0 + col, gy = y0 + rb * 8;
                 if (gx < W) {
                     unsigned *im = idmap + (size_t)v * W * Hc + (size_t)gx * Hc + gy;
+                    if (MODE == 2 && (Hc & 3) == 0 && gy + 8 <= Hc) {
+                        // the piece is 32 contiguous, 16-byte aligned bytes of the id map
+                        ((uint4 *)im)[0] = make_uint4(id[0] + 1u, id[1] + 1u, id[2] + 1u, id[3] + 1u);
+                        ((uint4 *)im)[1] = make_uint4(id[4] + 1u, id[5] + 1u, id[6] + 1u, id[7] + 1u);
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if ((MODE == 2 || id[k] != 0xffffffffu) && gy + k < Hc) im[k] = id[k] + 1u;
+                        for (int k = 0; k < 8; ++k)
+                            if ((MODE == 2 || id[k] != 0xffffffffu) && gy + k < Hc) im[k] = id[k] + 1u;
+                    }
                 }
             }
             if (MODE != 1) {
@@ -1266,184 +1272,353 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
 // point wins is a mapping (visibility.py:1190-1195)                           //
 // ------------------------------------------------------------------------- //
 // After the tile pass idmap[v][x][y] holds winner + 1 of every pixel of the
-// tiles that received a splat, and seen[i][v] the points that won a pixel.  A
-// point's pixels in a view lie inside its splat box, so a row of 16 lanes
-// walks the box of every seen (point, view) pair, column by column, and picks
-// the pixels the id map attributes to the point: once to count them, and, after
-// the CSR offsets are known, again to store them -- in ascending (x, y) order,
-// with no sort.  The boxes come from the records the binning count pass staged
-// (one block per 256 points and view), so nothing is projected again.
-// FILL = false: cnt[i][v] <- pixels of the pair inside the crop.
-// FILL = true: pixels[poff[i][v] ...] <- those pixels.
-#ifndef MVF_NE_ITEMS
-#define MVF_NE_ITEMS 8
-#endif
-constexpr int NE_ITEMS = MVF_NE_ITEMS;     // id-map reads of a box in flight per lane
+// tiles that received a splat (the other tiles hold stale words and are never
+// read: the marking pass walks the list of non-empty tiles), and seen[i][v] the
+// points that won a pixel.  The visible part of a splat is often a sliver of its
+// box (C2: 32 M pixels won out of 170 M box pixels), and boxes range from one
+// pixel to tens of thousands, so no pass walks boxes pixel by pixel:
+//  1. ne_box_kernel: every seen (point, view) pair gets room for one verdict bit
+//     per pixel of its splat box, as one byte ("entry") per column and group of
+//     8 image rows (rows 8g .. 8g + 7), columns first: ascending (x, y) is
+//     ascending (entry, bit).  Eight entries make a 64-bit word; the pair's words
+//     are also cut into chunks of NE_CHUNK words, the work items of step 5.
+//  2. ne_mark_kernel: a thread owns 8 vertically adjacent pixels (one row group
+//     of a column), hence the entry of every winner it meets: plain byte stores.
+//  3. a prefix sum of the bit counts of the words (bits_before[w] = bits of the
+//     words in front of word w): the pixels in front of an entry are bits_before
+//     of its word plus the bits below it in the word.  The pixels of a pair are
+//     the difference over its entries.
+//  4. ne_count_kernel, ne_point_kernel, ne_fill_kernel: CSR offsets.
+//  5. ne_emit_kernel: a lane takes one word of a chunk, rebuilds the pixels of
+//     its set bits from the pair's box, and the pixels of a chunk go out as one
+//     contiguous piece of the output.  No sort, no second look at the id map.
+// Pair records are laid out [view][point position].
+constexpr unsigned NE_NO_MASKS = 0xffffffffu;      // as first entry: the pair's entries did not fit the buffer
+constexpr int NE_CHUNK = 16;                       // words per chunk: a row of 16 lanes
 
-// A box is walked as (column, 16-row piece) items in ascending (x, y) order.
-// The items [first, first + NE_ITEMS) of box b for one row of 16 lanes: the
-// id-map reads are independent and go out together; then, item by item, the
-// lanes' verdicts as a 16-bit mask.  Returns the pixels of the items that the
-// id map attributes to `id` (inside the crop).
-struct NeItems { unsigned m[NE_ITEMS]; int px[NE_ITEMS], py[NE_ITEMS]; };
-struct NeView { const unsigned *idmap; int v, W, Hc, crop_top, crop_w, crop_h, off_x, off_y; };
-
-__device__ __forceinline__ unsigned ne_eval(
-    const TileEntry &b, unsigned id, const NeView &S, int first, int n_items, int nch, unsigned ly,
-    unsigned sh, NeItems &I)
+// x: first entry; y: first column | first row group << 16; z, w: low 32 and (in
+// the low half of w) high 16 bits of the pair's first pixel in the output minus
+// the pixels in front of its first entry (ne_fill_kernel); upper half of w: row
+// groups per column.
+typedef uint4 NePair;
+__device__ __forceinline__ unsigned ne_groups(unsigned ya, unsigned yb) { return ((yb - 1u) >> 3) - (ya >> 3) + 1u; }
+__device__ __forceinline__ unsigned ne_items(unsigned xa, unsigned xb, unsigned ya, unsigned yb)
 {
-    int cx = first / nch, cy = first - cx * nch;          // column and piece of the next item
-    unsigned val[NE_ITEMS];
-    bool in[NE_ITEMS];
-#pragma unroll
-    for (int k = 0; k < NE_ITEMS; ++k) {
-        const int x = (int)b.xa + cx, y = (int)b.ya + 16 * cy + (int)ly;
-        I.px[k] = x - S.off_x;
-        I.py[k] = y + S.crop_top - S.off_y;
-        in[k] = first + k < n_items && y < (int)b.yb && I.px[k] >= 0 && I.px[k] < S.crop_w &&
-                I.py[k] >= 0 && I.py[k] < S.crop_h;
-        val[k] = in[k] ? S.idmap[((size_t)S.v * S.W + x) * S.Hc + y] : 0u;
-        if (++cy == nch) { cy = 0; ++cx; }
-    }
-    unsigned count = 0;
-#pragma unroll
-    for (int k = 0; k < NE_ITEMS; ++k) {
-        const bool ok = in[k] && val[k] == id + 1u;
-        I.m[k] = (unsigned)(__ballot(ok) >> sh) & 0xffffu;      // this row of 16 lanes
-        count += __popc(I.m[k]);
-    }
-    return count;
+    return xb > xa && yb > ya ? (xb - xa) * ne_groups(ya, yb) : 0u;
 }
-
-// Stores the pixels of evaluated items from position `pos` on.
-__device__ __forceinline__ void ne_emit(
-    const NeItems &I, i64 pos, unsigned ly, int16_t *__restrict__ pixels, i64 pix_capacity)
+__device__ __forceinline__ unsigned ne_entry(const NePair &p, unsigned x, unsigned y)
 {
+    return p.x + (x - (p.y & 0xffffu)) * (p.w >> 16) + ((y >> 3) - (p.y >> 16));
+}
+__device__ __forceinline__ i64 ne_first_pixel(const NePair &p)
+{
+    return (i64)(((u64)(i64)(int16_t)(p.w & 0xffffu) << 32) | p.z);
+}
+// One block per NE_BOX_GROUP x 256 points and view (the records the binning count
+// pass staged, NE_BOX_GROUP of its blocks).  A pair's entries start at a word (its
+// count is rounded up to 8: no word holds entries of two pairs).  Entries and
+// chunks are handed out with one atomic each per block (atomics on one address
+// take their turns at the memory side, hence the grouping); cursor[0] ends as
+// the number of entries the call needs, cursor[1] as the number of chunks.
+// A chunk: x = pair, y = first word, z = words (1 .. NE_CHUNK), w = view.
+constexpr int NE_BOX_GROUP = 8;
+__global__ __launch_bounds__(256) void ne_box_kernel(
+    const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count, unsigned staged_blocks,
+    const uint8_t *__restrict__ seen, i64 seen_stride, i64 n, NePair *__restrict__ pairs,
+    uint4 *__restrict__ chunks, i64 mask_capacity, u64 *__restrict__ cursor, i64 *__restrict__ counters)
+{
+    __shared__ u64 s_base[2];
+    const int tid = threadIdx.x, v = blockIdx.y;
+    TileEntry e[NE_BOX_GROUP];
+    unsigned items[NE_BOX_GROUP];
+    bool have[NE_BOX_GROUP];
 #pragma unroll
-    for (int k = 0; k < NE_ITEMS; ++k) {
-        if ((I.m[k] >> ly) & 1u) {
-            const i64 at = pos + __popc(I.m[k] & ((1u << ly) - 1u));
-            if (at < pix_capacity) { pixels[2 * at] = (int16_t)I.px[k]; pixels[2 * at + 1] = (int16_t)I.py[k]; }
+    for (int g = 0; g < NE_BOX_GROUP; ++g) {
+        const unsigned sb = blockIdx.x * NE_BOX_GROUP + g;
+        have[g] = false;
+        e[g].key = 0; e[g].xa = e[g].xb = e[g].ya = e[g].yb = 0;
+        if (sb < staged_blocks) {
+            const size_t blk = (size_t)v * staged_blocks + sb;
+            if ((unsigned)tid < staged_count[blk]) { e[g] = staged[blk * 256 + tid]; have[g] = true; }
         }
-        pos += __popc(I.m[k]);
+    }
+    u64 mine = 0;
+#pragma unroll
+    for (int g = 0; g < NE_BOX_GROUP; ++g) {
+        have[g] = have[g] && seen[(size_t)(unsigned)e[g].key * seen_stride + v] != 0;
+        items[g] = have[g] ? (ne_items(e[g].xa, e[g].xb, e[g].ya, e[g].yb) + 7u) & ~7u : 0u;
+        mine += items[g];
+    }
+    u64 all;
+    const u64 before = block_exclusive_scan<u64>(mine, all);
+    if (all == 0) return;
+    if (tid == 0) s_base[0] = atomicAdd((unsigned long long *)cursor, (unsigned long long)all);
+    __syncthreads();
+    // the pairs' places, and the chunks they make
+    u64 mo = s_base[0] + before;
+    unsigned first[NE_BOX_GROUP], my_chunks = 0;
+    bool over = false;
+#pragma unroll
+    for (int g = 0; g < NE_BOX_GROUP; ++g) {
+        first[g] = NE_NO_MASKS;
+        if (items[g]) {
+            if (mo + items[g] <= (u64)mask_capacity) {
+                first[g] = (unsigned)mo;
+                my_chunks += ((items[g] >> 3) + NE_CHUNK - 1u) / NE_CHUNK;
+            } else {
+                over = true;
+            }
+        }
+        mo += items[g];
+    }
+    unsigned all_chunks;
+    const unsigned chunks_before = block_exclusive_scan<unsigned>(my_chunks, all_chunks);
+    if (tid == 0 && all_chunks) s_base[1] = atomicAdd((unsigned long long *)(cursor + 1), (unsigned long long)all_chunks);
+    const bool any_over = __syncthreads_or(over);
+    u64 at = s_base[1] + chunks_before;
+#pragma unroll
+    for (int g = 0; g < NE_BOX_GROUP; ++g) {
+        if (!have[g]) continue;
+        const size_t pair = (size_t)v * n + (unsigned)e[g].key;
+        pairs[pair] = make_uint4(first[g], (unsigned)e[g].xa | ((unsigned)e[g].ya >> 3) << 16, 0u,
+                                 (items[g] ? ne_groups(e[g].ya, e[g].yb) : 0u) << 16);
+        if (first[g] == NE_NO_MASKS) continue;
+        const unsigned words = items[g] >> 3;
+        for (unsigned w = 0; w < words; w += NE_CHUNK)
+            chunks[at++] = make_uint4((unsigned)pair, (first[g] >> 3) + w,
+                                      words - w < (unsigned)NE_CHUNK ? words - w : (unsigned)NE_CHUNK, (unsigned)v);
+    }
+    if (any_over && tid == 0) atomicOr((unsigned long long *)&counters[2], 8ull);
+}
+
+struct NeImage { const unsigned *idmap; int W, Hc, crop_top, crop_w, crop_h; i64 n; };
+
+// A thread takes the row group rg (8 rows) of column `col` of a non-empty tile;
+// a block 256 such pieces.  Adjacent lanes take adjacent row groups of a column.
+constexpr int NE_MARK_BLOCKS = TILE_X * TILE_Y / 8 / 256;
+__global__ __launch_bounds__(256) void ne_mark_kernel(
+    const TileDesc *__restrict__ descs, const unsigned *__restrict__ n_desc, NeImage S,
+    const mvf_view *__restrict__ views, const NePair *__restrict__ pairs, uint8_t *__restrict__ verdicts)
+{
+    constexpr int RGS = TILE_Y / 8;
+    const unsigned d = blockIdx.x / NE_MARK_BLOCKS;
+    if (d >= *n_desc) return;
+    const TileDesc D = descs[d];
+    const unsigned piece = (blockIdx.x % NE_MARK_BLOCKS) * 256u + threadIdx.x;
+    const int x = (int)(D.origin & 0xffffu) + (int)(piece / RGS);
+    const int y = (int)(D.origin >> 16) + (int)(piece % RGS) * 8;
+    if (x >= S.W || y >= S.Hc) return;
+    const int v = (int)D.view;
+    const int px = x - views[v].crop_off_x, py0 = y + S.crop_top - views[v].crop_off_y;
+    if (px < 0 || px >= S.crop_w) return;
+    const unsigned *im = S.idmap + ((size_t)v * S.W + x) * S.Hc + y;
+    unsigned val[8];
+    if ((S.Hc & 3) == 0 && y + 8 <= S.Hc) {
+        const uint4 a = ((const uint4 *)im)[0], b = ((const uint4 *)im)[1];
+        val[0] = a.x; val[1] = a.y; val[2] = a.z; val[3] = a.w;
+        val[4] = b.x; val[5] = b.y; val[6] = b.z; val[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val[k] = y + k < S.Hc ? im[k] : 0u;
+    }
+    // pixels outside the crop count as empty
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (py0 + k < 0 || py0 + k >= S.crop_h) val[k] = 0u;
+    // one entry per distinct winner: the first pixel of every winner leads
+    NePair pr[8];
+    unsigned bits[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bool lead = val[k] != 0u;
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < k && val[j] == val[k]) lead = false;
+            if (val[j] == val[k]) m |= 1u << j;
+        }
+        bits[k] = lead ? m : 0u;
+        pr[k] = make_uint4(NE_NO_MASKS, 0u, 0u, 0u);
+        if (lead) pr[k] = pairs[(size_t)v * S.n + (val[k] - 1u)];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (bits[k] != 0u && pr[k].x != NE_NO_MASKS)
+            verdicts[ne_entry(pr[k], (unsigned)x, (unsigned)y)] = (uint8_t)bits[k];
+}
+
+// bits_before[w] <- set bits of the 64-bit words [0, w), for w up to the number
+// of words in use (inclusive): block sums, then (after a scan of the block sums)
+// the words' own places.  Eight words per thread.
+constexpr int NE_SCAN_WORDS = 256 * 8;
+__device__ __forceinline__ i64 ne_words_used(const u64 *cursor, i64 mask_capacity)
+{
+    const u64 c = *cursor;
+    return ((c < (u64)mask_capacity ? (i64)c : mask_capacity) + 7) >> 3;
+}
+
+__device__ __forceinline__ unsigned ne_load_words(const u64 *verdicts, i64 base, i64 n, unsigned (&c)[8])
+{
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c[k] = 0u;
+    if (base < n) {
+        const uint4 *q = (const uint4 *)(verdicts + base);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 m = q[k];
+            c[2 * k] = __popc(m.x) + __popc(m.y);
+            c[2 * k + 1] = __popc(m.z) + __popc(m.w);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += c[k];
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void ne_bits_reduce_kernel(
+    const u64 *__restrict__ verdicts, const u64 *__restrict__ cursor, i64 mask_capacity,
+    unsigned *__restrict__ block_sums)
+{
+    const i64 n = ne_words_used(cursor, mask_capacity);
+    const i64 base = ((i64)blockIdx.x * 256 + threadIdx.x) * 8;
+    unsigned c[8];
+    const unsigned s = (i64)blockIdx.x * NE_SCAN_WORDS < n ? ne_load_words(verdicts, base, n, c) : 0u;
+    unsigned total;
+    block_exclusive_scan<unsigned>(s, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(256) void ne_bits_apply_kernel(
+    const u64 *__restrict__ verdicts, const u64 *__restrict__ cursor, i64 mask_capacity,
+    const unsigned *__restrict__ block_sums, unsigned *__restrict__ bits_before)
+{
+    const i64 n = ne_words_used(cursor, mask_capacity);
+    if ((i64)blockIdx.x * NE_SCAN_WORDS > n) return;
+    const i64 base = ((i64)blockIdx.x * 256 + threadIdx.x) * 8;
+    unsigned c[8];
+    const unsigned s = ne_load_words(verdicts, base, n, c);
+    unsigned total;
+    unsigned run = block_exclusive_scan<unsigned>(s, total) + block_sums[blockIdx.x];
+    if (base > n) return;
+    unsigned o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { o[k] = run; run += c[k]; }
+    if (base + 8 <= n) {
+        *(uint4 *)(bits_before + base) = make_uint4(o[0], o[1], o[2], o[3]);
+        *(uint4 *)(bits_before + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (base + k <= n) bits_before[base + k] = o[k];
     }
 }
 
-// NE_NO_MASKS in moff: the pair's verdicts did not fit the mask buffer.
-constexpr unsigned NE_NO_MASKS = 0xffffffffu;
-
-// FILL = false also stores the verdicts (bitmask, 8 entries = 16 bytes at a time; a pair's
-// entries start at a multiple of 8, reserved per block with one atomic on *mask_cursor) and
-// where they are (moff[i][v]).  FILL = true reads them back: a lane takes one entry (16
-// pixels of a column), a 16-lane prefix sum of the pixel counts gives its place, and it stores
-// its pixels -- one 32-byte read per 16 entries where the first scan reads 16 id-map words per
-// entry.
-template <bool FILL>
-__global__ __launch_bounds__(256) void ne_scan_kernel(
+// cnt[v][i] <- pixels of every seen pair inside the crop (same blocks as the binning passes).
+__global__ __launch_bounds__(256) void ne_count_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count,
-    const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ idmap,
-    const mvf_view *__restrict__ views, int W, int Hc, int crop_top, int crop_w, int crop_h, int V,
-    unsigned *__restrict__ cnt, const i64 *__restrict__ poff, int16_t *__restrict__ pixels,
-    i64 pix_capacity, unsigned short *__restrict__ bitmask, unsigned *__restrict__ moff,
-    i64 mask_capacity, unsigned *__restrict__ mask_cursor)
+    const uint8_t *__restrict__ seen, i64 seen_stride, i64 n, const NePair *__restrict__ pairs,
+    const unsigned *__restrict__ bits_before, unsigned *__restrict__ cnt)
 {
-    __shared__ TileEntry list[256];
-    __shared__ unsigned s_ioff[256];
-    __shared__ unsigned s_mbase;
     const int tid = threadIdx.x, v = blockIdx.y;
     const size_t blk = (size_t)v * gridDim.x + blockIdx.x;
-    const unsigned n = staged_count[blk];
-    if (n == 0) return;
-    TileEntry e;
-    e.key = 0; e.xa = e.xb = e.ya = e.yb = 0;
-    bool have = false;
-    if ((unsigned)tid < n) {
-        e = staged[blk * 256 + tid];
-        have = seen[(size_t)(unsigned)e.key * seen_stride + v] != 0;
-    }
-    unsigned total;
-    const unsigned rank = block_rank_flag(have, total);
-    if (have) list[rank] = e;
-    __syncthreads();
-    const unsigned quarter = tid >> 4, ly = tid & 15, sh = 16u * ((tid >> 4) & 3u);
-    const NeView S{idmap, v, W, Hc, crop_top, crop_w, crop_h, views[v].crop_off_x, views[v].crop_off_y};
-    auto items_of = [](const TileEntry &b, int &nch) {
-        nch = ((int)b.yb - (int)b.ya + 15) >> 4;
-        return ((int)b.xb - (int)b.xa) * nch;
-    };
-    if (!FILL) {
-        // room for the verdicts of the block's pairs: entries of a pair rounded up to 8
-        unsigned mine = 0;
-        if ((unsigned)tid < total) { int nch; mine = ((unsigned)items_of(list[tid], nch) + 7u) & ~7u; }
-        unsigned all;
-        const unsigned before = block_exclusive_scan<unsigned>(mine, all);
-        s_ioff[tid] = before;
-        if (tid == 0) s_mbase = atomicAdd(mask_cursor, all);
-        __syncthreads();
-    }
-    // one box per row of 16 lanes
-    for (unsigned r = quarter; r < total; r += 16u) {
-        const TileEntry b = list[r];
-        int nch;
-        const int n_items = items_of(b, nch);
-        const unsigned id = (unsigned)b.key;
-        const i64 base = FILL ? poff[(size_t)id * V + v] : 0;
-        unsigned count = 0;
-        if (!FILL) {
-            const i64 mo = (i64)s_mbase + s_ioff[r];
-            const bool keep = mo + (((i64)n_items + 7) & ~(i64)7) <= mask_capacity && (i64)s_mbase + s_ioff[r] < 0xffffffffll;
-            for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
-                NeItems I;
-                count += ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
-                static_assert(NE_ITEMS == 8, "eight 16-bit verdicts are one 16-byte store");
-                if (keep && ly == 0)
-                    *(uint4 *)(bitmask + mo + t0) = make_uint4(I.m[0] | I.m[1] << 16, I.m[2] | I.m[3] << 16,
-                                                               I.m[4] | I.m[5] << 16, I.m[6] | I.m[7] << 16);
-            }
-            if (ly == 0) {
-                cnt[(size_t)id * V + v] = count;
-                moff[(size_t)id * V + v] = keep ? (unsigned)mo : NE_NO_MASKS;
-            }
-            continue;
+    if ((unsigned)tid >= staged_count[blk]) return;
+    const TileEntry e = staged[blk * 256 + tid];
+    const unsigned id = (unsigned)e.key;
+    if (seen[(size_t)id * seen_stride + v] == 0) return;
+    const size_t pair = (size_t)v * n + id;
+    const unsigned mo = pairs[pair].x;
+    // (a pair's entries are whole words)
+    cnt[pair] = mo == NE_NO_MASKS ? 0u
+        : bits_before[(mo >> 3) + ((ne_items(e.xa, e.xb, e.ya, e.yb) + 7u) >> 3)] - bits_before[mo >> 3];
+}
+
+// pixels <- the pixels of all pairs.  A wave takes 4 chunks (up to NE_CHUNK words
+// of one pair each), a lane one word: it rebuilds the pixels of the word's set
+// bits from the pair's box and lays them out, in LDS, where they stand among the
+// wave's pixels; the pixels of a chunk are neighbours in the output (entry order
+// is pixel order), so the wave then stores with consecutive lanes on consecutive
+// pixels.  The grid is fixed; waves stride over the chunk list, fetching chunk
+// and pair record one round ahead of their use.
+constexpr int NE_EMIT_SLOTS = 1024;          // pixels of a wave staged at a time
+__global__ __launch_bounds__(256) void ne_emit_kernel(
+    const uint4 *__restrict__ chunks, const u64 *__restrict__ cursor, const NePair *__restrict__ pairs,
+    const u64 *__restrict__ verdicts, const unsigned *__restrict__ bits_before,
+    const mvf_view *__restrict__ views, int crop_top, unsigned *__restrict__ pixels, i64 pix_capacity)
+{
+    __shared__ unsigned s_pix[4][NE_EMIT_SLOTS + 64];     // + one spare slot per lane
+    const u64 nc = cursor[1];
+    const unsigned n_chunks = nc < 0xffffffffull ? (unsigned)nc : 0xffffffffu;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned sub = lane / NE_CHUNK, wl = lane % NE_CHUNK;
+    constexpr unsigned PER_WAVE = 64 / NE_CHUNK;
+    static_assert(PER_WAVE == 4, "four chunks per wave");
+    const u64 stride = (u64)gridDim.x * 4u * PER_WAVE;
+    const uint4 no_chunk = make_uint4(0u, 0u, 0u, 0u);
+    u64 c0 = ((u64)blockIdx.x * 4u + wave) * PER_WAVE;
+    uint4 ch = c0 + sub < n_chunks ? chunks[c0 + sub] : no_chunk;
+    NePair pr = wl < ch.z ? pairs[ch.x] : no_chunk;
+    for (; c0 < n_chunks; c0 += stride) {
+        const uint4 ch_next = c0 + stride + sub < n_chunks ? chunks[c0 + stride + sub] : no_chunk;
+        u64 bits = 0;
+        unsigned at = 0, col = 0, rg = 0, nrg = 1, xa = 0, g0 = 0;
+        int off_x = 0, off_y = 0;
+        if (wl < ch.z) {
+            const unsigned w = ch.y + wl;
+            nrg = pr.w >> 16;
+            xa = pr.y & 0xffffu;
+            g0 = pr.y >> 16;
+            off_x = views[ch.w].crop_off_x;
+            off_y = views[ch.w].crop_off_y - crop_top;
+            bits = verdicts[w];
+            at = (unsigned)(ne_first_pixel(pr) + (i64)bits_before[w]);
+            const unsigned rel = (w << 3) - pr.x;           // first entry of the word, inside the pair
+            col = rel / nrg;
+            rg = rel - col * nrg;
         }
-        const unsigned mo = moff[(size_t)id * V + v];
-        if (mo == NE_NO_MASKS) {
-            for (int t0 = 0; t0 < n_items; t0 += NE_ITEMS) {
-                NeItems I;
-                const unsigned c = ne_eval(b, id, S, t0, n_items, nch, ly, sh, I);
-                ne_emit(I, base + count, ly, pixels, pix_capacity);
-                count += c;
-            }
-            continue;
-        }
-        const int px0 = (int)b.xa - S.off_x, py0 = (int)b.ya + S.crop_top - S.off_y;
-        for (int t0 = 0; t0 < n_items; t0 += 16) {
-            const int t = t0 + (int)ly;
-            unsigned m = t < n_items ? (unsigned)bitmask[(size_t)mo + t] : 0u;
-            // place of the entry's pixels: prefix sum over the row of 16 lanes
-            const unsigned c = __popc(m);
-            unsigned inc = c;
+        const NePair pr_next = wl < ch_next.z ? pairs[ch_next.x] : no_chunk;
+        ch = ch_next;
+        pr = pr_next;
+        // place among the wave's pixels
+        const unsigned cnt = (unsigned)__popcll(bits);
+        unsigned inc = cnt;
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const unsigned o = __shfl_up(inc, d, 16);
-                if ((int)ly >= d) inc += o;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(inc, d, 64);
+            if ((int)lane >= d) inc += o;
+        }
+        const unsigned total = __shfl(inc, 63, 64);
+        const unsigned slot0 = inc - cnt;
+        // the pixels of a chunk are consecutive in the output: first slot and first place of each
+        const unsigned s1 = __shfl(slot0, 16, 64), s2 = __shfl(slot0, 32, 64), s3 = __shfl(slot0, 48, 64);
+        const unsigned a0 = __shfl(at, 0, 64), a1 = __shfl(at, 16, 64), a2 = __shfl(at, 32, 64), a3 = __shfl(at, 48, 64);
+        for (unsigned win = 0; win < total; win += NE_EMIT_SLOTS) {
+            // entry by entry (a byte of the word: one column, 8 rows), all lanes in step
+            unsigned slot = slot0 - win, c_ = col, r_ = rg;
+#pragma unroll 1
+            for (unsigned j = 0; j < 8u; ++j) {
+                const unsigned byte = (unsigned)(bits >> (8u * j)) & 0xffu;
+                const unsigned xy = ((unsigned)((int)(xa + c_) - off_x) & 0xffffu) | ((unsigned)((int)((g0 + r_) << 3) - off_y) << 16);
+                if (__ballot(byte != 0u)) {
+#pragma unroll
+                    for (unsigned b = 0; b < 8u; ++b) {
+                        // (a store per row and lane, to the lane's spare slot where the bit is clear
+                        // or the pixel is outside the window: no branch)
+                        const unsigned set = (byte >> b) & 1u;
+                        s_pix[wave][set && slot < (unsigned)NE_EMIT_SLOTS ? slot : NE_EMIT_SLOTS + lane] = xy + (b << 16);
+                        slot += set;
+                    }
+                }
+                if (++r_ == nrg) { r_ = 0; ++c_; }
             }
-            i64 at = base + count + (inc - c);
-            count += __shfl(inc, 15, 16);
-            if (m) {
-                int cx, cy;
-                if (nch == 1) { cx = t; cy = 0; }
-                else if (nch == 2) { cx = t >> 1; cy = t & 1; }
-                else { cx = t / nch; cy = t - cx * nch; }
-                const int16_t x = (int16_t)(px0 + cx);
-                const int y = py0 + 16 * cy;
-                do {
-                    const int j = __ffs(m) - 1;
-                    m &= m - 1;
-                    if (at < pix_capacity) { pixels[2 * at] = x; pixels[2 * at + 1] = (int16_t)(y + j); }
-                    ++at;
-                } while (m);
+            __builtin_amdgcn_wave_barrier();
+            const unsigned here = total - win < (unsigned)NE_EMIT_SLOTS ? total - win : (unsigned)NE_EMIT_SLOTS;
+            for (unsigned t = lane; t < here; t += 64) {
+                const unsigned sl = win + t;
+                const unsigned to = sl >= s3 ? a3 + (sl - s3) : sl >= s2 ? a2 + (sl - s2) : sl >= s1 ? a1 + (sl - s1) : a0 + sl;
+                if ((i64)to < pix_capacity) pixels[to] = s_pix[wave][t];
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -1451,7 +1626,7 @@ __global__ __launch_bounds__(256) void ne_scan_kernel(
 // One thread per output point id: the views that map it (won a pixel inside
 // the crop), as bit masks, and the block's numbers of view rows and pixels.
 __global__ __launch_bounds__(256) void ne_point_kernel(
-    const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ cnt, int V,
+    const uint8_t *__restrict__ seen, i64 seen_stride, const unsigned *__restrict__ cnt, i64 n, int V,
     const i64 *__restrict__ inv_ids, i64 num_points, unsigned *__restrict__ masks,
     unsigned *__restrict__ block_rows, i64 *__restrict__ block_pix, int *__restrict__ view_seen)
 {
@@ -1472,7 +1647,7 @@ __global__ __launch_bounds__(256) void ne_point_kernel(
             sm &= sm - 1;
             const int v = (wd << 5) + bit;
             view_seen[v] = 1;                       // mapped by the visibility model, cropped or not
-            const unsigned c = cnt[(size_t)i * V + v];
+            const unsigned c = cnt[(size_t)v * n + i];
             if (c) { kept |= 1u << bit; pix += c; }
         }
         if (q < num_points) masks[(size_t)wd * num_points + q] = kept;
@@ -1528,15 +1703,16 @@ __device__ __forceinline__ float repeat_add(float f, unsigned c)
 
 // Pointers, images, view pointers and view features (mean over the view's
 // pixels, which all carry the features of the point, summed one by one as a
-// segment mean does); poff[i][v] <- first pixel of the pair for the pixel pass.
+// segment mean does); the pair records receive the first pixel of the pair minus
+// the bits before its first entry, for the pixel pass.
 template <class Src>
 __global__ __launch_bounds__(256) void ne_fill_kernel(
     Src src, mvf_vis_params P, int V, const i64 *__restrict__ inv_ids, i64 num_points,
     const unsigned *__restrict__ masks, const unsigned *__restrict__ block_rows,
     const i64 *__restrict__ block_pix, const unsigned *__restrict__ cnt, const int *__restrict__ view_seen,
     FeatArgs A, i64 out_capacity, i64 pix_capacity, i64 *__restrict__ pointers, i64 *__restrict__ images,
-    i64 *__restrict__ view_ptr, float *__restrict__ features, i64 *__restrict__ poff,
-    i64 *__restrict__ counters)
+    i64 *__restrict__ view_ptr, float *__restrict__ features, NePair *__restrict__ pairs,
+    const unsigned *__restrict__ bits_before, const u64 *__restrict__ mask_cursor, i64 *__restrict__ counters)
 {
     extern __shared__ __align__(16) unsigned char dyn_lds[];   // V views, then V + 1 ranks
     src = views_to_lds(src, V, (mvf_view *)dyn_lds);
@@ -1554,6 +1730,7 @@ __global__ __launch_bounds__(256) void ne_fill_kernel(
 
     const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
     const i64 i = q < num_points ? inv_ids[q] : -1;
+    const i64 n = src.count();
     const int words = (V + 31) >> 5;
     unsigned rows = 0;
     i64 pix = 0;
@@ -1564,7 +1741,7 @@ __global__ __launch_bounds__(256) void ne_fill_kernel(
             while (m) {
                 const int v = (wd << 5) + __ffs(m) - 1;
                 m &= m - 1;
-                pix += cnt[(size_t)i * V + v];
+                pix += cnt[(size_t)v * n + i];
             }
         }
     unsigned rows_total;
@@ -1578,6 +1755,8 @@ __global__ __launch_bounds__(256) void ne_fill_kernel(
         counters[0] = n_rows;
         counters[3] = view_rank[V];
         counters[4] = n_pix;
+        counters[5] = (i64)mask_cursor[0];           // verdict entries the call needs
+        counters[6] = (i64)mask_cursor[1];           // chunks of the pixel pass
         if (n_rows > out_capacity) atomicOr((unsigned long long *)&counters[2], 1ull);
         if (n_pix > pix_capacity) atomicOr((unsigned long long *)&counters[2], 4ull);
     }
@@ -1590,8 +1769,15 @@ __global__ __launch_bounds__(256) void ne_fill_kernel(
         while (m) {
             const int v = (wd << 5) + __ffs(m) - 1;
             m &= m - 1;
-            const unsigned c = cnt[(size_t)i * V + v];
-            poff[(size_t)i * V + v] = p;
+            const unsigned c = cnt[(size_t)v * n + i];
+            {
+                // for the pixel pass: first pixel of the pair minus the pixels in front of its first entry
+                NePair pr = pairs[(size_t)v * n + i];
+                const i64 fp = p - (pr.x == NE_NO_MASKS ? 0 : (i64)bits_before[pr.x >> 3]);
+                pr.z = (unsigned)fp;
+                pr.w = (pr.w & 0xffff0000u) | ((unsigned)(fp >> 32) & 0xffffu);
+                pairs[(size_t)v * n + i] = pr;
+            }
             if (k < out_capacity) {
                 double x, y, fx, fy; float d;
                 src.get(i, v, P, x, y, d, fx, fy);
@@ -1928,6 +2114,18 @@ extern "C" int mvf_mapping_features(
 // two, at least 1024.
 static inline i64 centre_table_slots(i64 requested);
 
+// Entries of the verdict buffer of the plain-splat pass: the caller's number (0 = half
+// an entry, that is four bits, per pixel of the views: C2 needs 0.44), a multiple of 64
+// below 2^32.
+static inline i64 ne_mask_capacity(i64 requested, i64 map_pixels)
+{
+    i64 c = requested > 0 ? requested : map_pixels / 2;
+    c = (c + 63) & ~(i64)63;
+    if (c < 64) c = 64;
+    if (c > 0xfffffff0ll) c = 0xfffffff0ll;
+    return c;
+}
+
 // The buffers mvf_map_images_exact cuts out of the caller's workspace.
 struct MapWorkspace {
     i64 ncnt, seen_stride;
@@ -1937,18 +2135,18 @@ struct MapWorkspace {
     uint8_t *seen;
     CentreTable table;
     size_t clear_bytes, used;
-    // plain splat visibility only (map_pixels > 0): id map [V][W][Hc], pixel counts
-    // and first-pixel offsets of the (point, view) pairs [n][V], pixels per block
-    unsigned *idmap, *cnt;
-    i64 *poff, *block_pix;
-    // ... and the verdicts of the counting scan, 16 pixels of a box column per entry, with the
-    // place of every pair's entries: the second scan reads these instead of the id map
-    unsigned short *bitmask;
-    unsigned *moff;
+    // plain splat visibility only (map_pixels > 0): id map [V][W][Hc], pixel counts of the
+    // (point, view) pairs [V][n], pixels per block, and the verdict bits (one byte per entry)
+    // with their running counts per 8 entries, the pair records [V][n] and the chunk list
+    // (see ne_box_kernel)
+    unsigned *idmap, *cnt, *bits_blocks, *bits_before;
+    i64 *block_pix;
+    uint8_t *verdicts;
+    uint4 *ne_pairs, *ne_chunks;
     i64 mask_capacity;
     // Vw: views a point can meet (V, or the largest sample of a batched call)
     bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
-               i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0, int Vw = 0)
+               i64 pair_capacity, i64 centre_slots, i64 map_pixels = 0, int Vw = 0, i64 mask_entries = 0)
     {
         if (Vw <= 0) Vw = V;
         const i64 slots = centre_table_slots(centre_slots);
@@ -1972,21 +2170,22 @@ struct MapWorkspace {
         seen = ar.take<uint8_t>((size_t)seen_stride * n);
         masks = ar.take<unsigned>((size_t)words * num_points);
         block_sums = ar.take<unsigned>(cdiv(num_points, 256));
-        idmap = cnt = nullptr;
-        poff = block_pix = nullptr;
-        bitmask = nullptr;
-        moff = nullptr;
+        idmap = cnt = bits_blocks = bits_before = nullptr;
+        block_pix = nullptr;
+        verdicts = nullptr;
+        ne_pairs = ne_chunks = nullptr;
         mask_capacity = 0;
         if (map_pixels > 0) {
             idmap = ar.take<unsigned>((size_t)map_pixels);
             cnt = ar.take<unsigned>((size_t)n * V);
-            poff = ar.take<i64>((size_t)n * V);
             block_pix = ar.take<i64>(cdiv(num_points, 256));
-            // half an entry per pixel of the views (C2 needs a third; pairs beyond the
-            // capacity are scanned against the id map a second time)
-            mask_capacity = (map_pixels / 2 + 7) & ~(i64)7;
-            bitmask = ar.take<unsigned short>((size_t)mask_capacity);
-            moff = ar.take<unsigned>((size_t)n * V);
+            mask_capacity = ne_mask_capacity(mask_entries, map_pixels);
+            verdicts = ar.take<uint8_t>((size_t)mask_capacity + 64);
+            bits_before = ar.take<unsigned>((size_t)mask_capacity / 8 + 16);
+            bits_blocks = ar.take<unsigned>((size_t)cdiv(mask_capacity / 8 + 1, 2048) + 1);
+            ne_pairs = ar.take<uint4>((size_t)n * V);
+            // every pair at least one chunk, and one per NE_CHUNK words (128 entries)
+            ne_chunks = ar.take<uint4>((size_t)n * V + (size_t)mask_capacity / 128 + 1);
         }
         used = ar.off;
         return ar.ok();
@@ -2270,12 +2469,13 @@ extern "C" int mvf_map_images_depth(
 // binning and tile z-buffer as in the exact pass, then every pixel a point wins
 // becomes a mapping (no shared-pixel rule, no centre table).
 extern "C" size_t mvf_map_images_splat_workspace_bytes(
-    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity)
+    int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity,
+    int64_t mask_capacity)
 {
     const i64 tiles = (i64)V * ((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y);
     MapWorkspace ws;
     ws.carve(nullptr, 0, n > 0 ? n : 1, V, tiles, num_points > 0 ? num_points : 1,
-             pair_capacity > 0 ? pair_capacity : 1, 1, (i64)V * W * H);
+             pair_capacity > 0 ? pair_capacity : 1, 1, (i64)V * W * H, 0, mask_capacity);
     return ws.used;
 }
 
@@ -2284,8 +2484,8 @@ static int map_images_splat_impl(
     const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
     int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
     const float *linearity, const float *planarity, const float *scattering, const float *normals,
-    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers, int64_t *images,
-    int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t mask_capacity, int64_t *pointers,
+    int64_t *images, int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
     int64_t pix_capacity, int32_t *view_seen, int64_t *counters, void *workspace,
     size_t workspace_bytes, void *stream)
 {
@@ -2294,8 +2494,11 @@ static int map_images_splat_impl(
                 "map_images_splat: bad sizes n=%lld V=%d (at most %d views per call)", (long long)n, V, MI_MAX_VIEWS);
     MVF_REQUIRE(xyz && inv_ids && views && pointers && images && view_pointers && pixels && features &&
                 view_seen && counters, "map_images_splat: null buffer");
-    MVF_REQUIRE(crop_w >= 1 && crop_h >= 1 && pair_capacity >= 1 && out_capacity >= 0 && pix_capacity >= 0,
-                "map_images_splat: bad scalar argument");
+    MVF_REQUIRE(crop_w >= 1 && crop_h >= 1 && pair_capacity >= 1 && out_capacity >= 0 && pix_capacity >= 0 &&
+                mask_capacity >= 0, "map_images_splat: bad scalar argument");
+    MVF_REQUIRE((i64)n * V < 0xffffffffll, "map_images_splat: %lld points x %d views are too many for one call", (long long)n, V);
+    MVF_REQUIRE((i64)V * h_params->W * h_params->H < 0xffffffffll, "map_images_splat: %d views of %dx%d pixels are too many for one call",
+                V, h_params->W, h_params->H);
     const mvf_vis_params P = *h_params;
     hipStream_t st = (hipStream_t)stream;
     int tiles_x, tiles_y, Hc;
@@ -2304,7 +2507,8 @@ static int map_images_splat_impl(
     const i64 tiles = (i64)tiles_per_view * V;
     const i64 nb = cdiv(num_points, 256);
     MapWorkspace ws;
-    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, 1, (i64)V * P.W * Hc)) {
+    if (!ws.carve(workspace, workspace_bytes, n, V, tiles, num_points, pair_capacity, 1, (i64)V * P.W * Hc, 0,
+                  mask_capacity > 0 ? mask_capacity : ne_mask_capacity(0, (i64)V * P.W * P.H))) {
         set_error("map_images_splat: workspace too small (%zu < %zu)", workspace_bytes, ws.used);
         return MVF_E_WORKSPACE;
     }
@@ -2312,6 +2516,7 @@ static int map_images_splat_impl(
 
     prof_begin(st);
     MVF_HIP(hipMemsetAsync(ws.tile_count, 0, (size_t)(ncnt + BIN_TAIL) * sizeof(unsigned), st));
+    MVF_HIP(hipMemsetAsync(ws.verdicts, 0, (size_t)ws.mask_capacity + 64, st));
     prof_mark("memset", st);
     Src src{xyz, views, mask, (i64)n, cylinder};
     dim3 grid_nv(cdiv(n, 256), V), block(256);
@@ -2331,25 +2536,43 @@ static int map_images_splat_impl(
                        ws.descs, ws.tile_count + ncnt, ws.tile_count + ncnt + ZB_QUEUE_STRIDE, (i64)pair_capacity,
                        tiles_y, tiles_per_view, P.W, Hc, ws.seen, ws.seen_stride, ws.idmap, (const int *)nullptr);
     prof_mark("tile_zbuffer", st);
-    hipLaunchKernelGGL((ne_scan_kernel<false>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
-                       ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
-                       (const i64 *)nullptr, (int16_t *)nullptr, (i64)0, ws.bitmask, ws.moff, ws.mask_capacity,
-                       ws.tile_count + ncnt + NE_CURSOR_SLOT);
+    u64 *cursor = (u64 *)(ws.tile_count + ncnt + NE_CURSOR_SLOT);        // [0] entries, [1] chunks
+    const uint8_t *cseen = ws.seen;
+    const unsigned *n_desc = ws.tile_count + ncnt;
+    const u64 *verdicts = (const u64 *)ws.verdicts;
+    const NeImage img{ws.idmap, P.W, Hc, P.crop_top, crop_w, crop_h, (i64)n};
+    hipLaunchKernelGGL(ne_box_kernel, dim3(cdiv(grid_nv.x, NE_BOX_GROUP), V), block, 0, st, ws.staged, ws.staged_count,
+                       grid_nv.x, cseen, ws.seen_stride, (i64)n, ws.ne_pairs, ws.ne_chunks, ws.mask_capacity, cursor,
+                       (i64 *)counters);
+    prof_mark("pixel_boxes", st);
+    hipLaunchKernelGGL(ne_mark_kernel, dim3((unsigned)(tiles * NE_MARK_BLOCKS)), block, 0, st, ws.descs, n_desc, img,
+                       views, (const NePair *)ws.ne_pairs, ws.verdicts);
+    prof_mark("pixel_mark", st);
+    const unsigned scan_blocks = (unsigned)cdiv(ws.mask_capacity / 8 + 1, NE_SCAN_WORDS);
+    hipLaunchKernelGGL(ne_bits_reduce_kernel, dim3(scan_blocks), block, 0, st, verdicts, cursor, ws.mask_capacity,
+                       ws.bits_blocks);
+    hipLaunchKernelGGL((scan_spine_kernel<unsigned, i64>), dim3(1), dim3(SCAN_BLOCK), 0, st, ws.bits_blocks,
+                       (i64)scan_blocks, (i64 *)nullptr);
+    hipLaunchKernelGGL(ne_bits_apply_kernel, dim3(scan_blocks), block, 0, st, verdicts, cursor, ws.mask_capacity,
+                       (const unsigned *)ws.bits_blocks, ws.bits_before);
+    prof_mark("pixel_scan", st);
+    hipLaunchKernelGGL(ne_count_kernel, grid_nv, block, 0, st, ws.staged, ws.staged_count, cseen, ws.seen_stride,
+                       (i64)n, (const NePair *)ws.ne_pairs, (const unsigned *)ws.bits_before, ws.cnt);
     prof_mark("pixel_count", st);
     dim3 grid_q((unsigned)nb);
-    hipLaunchKernelGGL(ne_point_kernel, grid_q, block, 0, st, ws.seen, ws.seen_stride, ws.cnt, V,
+    hipLaunchKernelGGL(ne_point_kernel, grid_q, block, 0, st, ws.seen, ws.seen_stride, ws.cnt, (i64)n, V,
                        (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix, view_seen);
     prof_mark("point_mask", st);
     hipLaunchKernelGGL((ne_fill_kernel<Src>), grid_q, block, (size_t)V * sizeof(mvf_view) + (size_t)(V + 1) * sizeof(int), st,
                        src, P, V, (const i64 *)inv_ids, (i64)num_points, ws.masks, ws.block_sums, ws.block_pix,
                        ws.cnt, view_seen, feat_args(linearity, planarity, scattering, normals, P.H, P.r_max, P.r_min),
                        (i64)out_capacity, (i64)pix_capacity, (i64 *)pointers, (i64 *)images, (i64 *)view_pointers,
-                       features, ws.poff, (i64 *)counters);
+                       features, ws.ne_pairs, (const unsigned *)ws.bits_before, cursor, (i64 *)counters);
     prof_mark("csr_fill", st);
-    hipLaunchKernelGGL((ne_scan_kernel<true>), grid_nv, block, 0, st, ws.staged, ws.staged_count, ws.seen,
-                       ws.seen_stride, ws.idmap, views, P.W, Hc, P.crop_top, crop_w, crop_h, V, ws.cnt,
-                       (const i64 *)ws.poff, pixels, (i64)pix_capacity, ws.bitmask, ws.moff, ws.mask_capacity,
-                       (unsigned *)nullptr);
+    // a fixed grid that fills the device; the waves stride over the chunks
+    hipLaunchKernelGGL(ne_emit_kernel, dim3(256 * 8), block, 0, st, (const uint4 *)ws.ne_chunks, cursor,
+                       (const NePair *)ws.ne_pairs, verdicts, (const unsigned *)ws.bits_before, views, P.crop_top,
+                       (unsigned *)pixels, (i64)pix_capacity);
     prof_mark("pixel_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
@@ -2359,14 +2582,14 @@ extern "C" int mvf_map_images_splat(
     const float *xyz, const int64_t *inv_ids, int64_t n, int64_t num_points, const mvf_view *views,
     int32_t V, const mvf_vis_params *h_params, int32_t cylinder, const uint8_t *mask,
     const float *linearity, const float *planarity, const float *scattering, const float *normals,
-    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t *pointers, int64_t *images,
-    int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
+    int32_t crop_w, int32_t crop_h, int64_t pair_capacity, int64_t mask_capacity, int64_t *pointers,
+    int64_t *images, int64_t *view_pointers, int16_t *pixels, float *features, int64_t out_capacity,
     int64_t pix_capacity, int32_t *view_seen, int64_t *counters, void *workspace,
     size_t workspace_bytes, void *stream)
 {
     if (h_params && h_params->camera >= MVF_CAM_KITTI360_FISHEYE)
         return map_images_splat_impl<CloudSrcAny>(
-            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
+            xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, mask_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
     return map_images_splat_impl<CloudSrc>(
-        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
+        xyz, inv_ids, n, num_points, views, V, h_params, cylinder, mask, linearity, planarity, scattering, normals, crop_w, crop_h, pair_capacity, mask_capacity, pointers, images, view_pointers, pixels, features, out_capacity, pix_capacity, view_seen, counters, workspace, workspace_bytes, stream);
 }

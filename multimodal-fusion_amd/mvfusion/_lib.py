@@ -87,9 +87,9 @@ _SIGNATURES = {
     "mvf_map_images_exact_batch": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _I32, _I32, _P, _I32, _P,
                                              _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64,
                                              _P, _P, _P, _P, _I64, _P, _P, _P, _SZ, _P]),
-    "mvf_map_images_splat_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I64, _I64]),
+    "mvf_map_images_splat_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32, _I64, _I64, _I64]),
     "mvf_map_images_splat": (C.c_int, [_P, _P, _I64, _I64, _P, _I32, _P, _I32, _P, _P, _P, _P, _P,
-                                       _I32, _I32, _I64, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P,
+                                       _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P,
                                        _SZ, _P]),
     "mvf_profile_zbuffer_ops": (C.c_int, [_P, _SZ, _I64, _I32, _P, _I64, _I64, _I64, _P, _P]),
     "mvf_map_images_depth_workspace_bytes": (_SZ, [_I64, _I32]),

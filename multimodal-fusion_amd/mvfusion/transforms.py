@@ -226,7 +226,7 @@ class FusedMapPlan:
     def __init__(self, pos, ids, inv, attrs, views, mask, params, cylinder, upscale,
                  downscale, crop_size, V, num_points, device, pair_cap=None, out_cap=None,
                  lane=0, centre_slots=None, depth_maps=None, pix_cap=None, window=None,
-                 view_first=None, views_per_point=None):
+                 view_first=None, views_per_point=None, mask_cap=None):
         self.pos, self.ids, self.inv, self.attrs = pos, ids, inv, attrs
         # a batch of samples in one pass (mvf_map_images_exact_batch): window
         # [N, 2] int32 = (first view, number of views) of every point position,
@@ -251,6 +251,9 @@ class FusedMapPlan:
         # a mapping; room for that many pixels (at most one per image pixel)
         self.splat = depth_maps is None and not params.exact
         self.pix_cap = pix_cap or (V * params.W * params.H // 2)
+        # ... and for the pass's verdict bits: one 8-pixel entry per column and group of
+        # 8 image rows of the splat boxes of the pairs that win a pixel
+        self.mask_cap = mask_cap or (V * params.W * params.H // 4)
         self._slots = [None] * self.SLOTS
         self._ws = None
         self._turn = 0
@@ -302,7 +305,8 @@ class FusedMapPlan:
             self.cylinder, self.upscale, self.downscale, self.crop_size, self.V,
             self.num_points, self.device, self.pair_cap, self.out_cap, lane=lane,
             centre_slots=self.centre_slots, depth_maps=self.depth_maps, pix_cap=self.pix_cap,
-            window=self.window, view_first=self.view_first, views_per_point=self.views_per_point)
+            window=self.window, view_first=self.view_first, views_per_point=self.views_per_point,
+            mask_cap=self.mask_cap)
 
     def _slot(self, k):
         """Output buffers of slot k: (capacities, counters, host counters, event,
@@ -327,14 +331,15 @@ class FusedMapPlan:
         return sl
 
     def _workspace(self):
-        key = (self.pair_cap, self.centre_slots)
+        key = (self.pair_cap, self.centre_slots, self.mask_cap if self.splat else 0)
         if self._ws is None or self._ws[0] != key:
             lib = L.load()
             if self.depth_maps is not None:
                 ws_bytes = lib.mvf_map_images_depth_workspace_bytes(self.num_points, self.V)
             elif self.splat:
                 ws_bytes = lib.mvf_map_images_splat_workspace_bytes(
-                    self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap)
+                    self.N, self.V, self.params.W, self.params.H, self.num_points, self.pair_cap,
+                    self.mask_cap)
             elif self.window is not None:
                 ws_bytes = lib.mvf_map_images_batch_workspace_bytes(
                     self.N, self.V, self.views_per_point, self.params.W, self.params.H,
@@ -361,7 +366,8 @@ class FusedMapPlan:
                     L.ptr(self.pos), L.ptr(self.inv), self.N, self.num_points, L.ptr(self.views),
                     self.V, C.byref(P), int(self.cylinder), L.ptr(self.mask),
                     *[L.ptr(a) for a in self.attrs], int(self.crop_size[0]), int(self.crop_size[1]),
-                    self.pair_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(view_ptr), L.ptr(pixels),
+                    self.pair_cap, self.mask_cap, L.ptr(pointers), L.ptr(img_ids), L.ptr(view_ptr),
+                    L.ptr(pixels),
                     L.ptr(feats), self.out_cap, self.pix_cap, L.ptr(view_seen), L.ptr(counters),
                     L.ptr(ws), ws.numel(), L.stream_ptr(self.device)))
             return sl
@@ -420,9 +426,10 @@ class FusedMapPlan:
         if pow2(target) != pow2(self.centre_slots):
             self.centre_slots = target
 
-    def _grow(self, n_map, pairs, overflow=1, n_pix=0):
+    def _grow(self, n_map, pairs, overflow=1, n_pix=0, n_mask=0):
         """Larger buffers after an overflow (bit 0: pairs / outputs, bit 1: the
-        centre-pixel table, bit 2: pixels of the plain splat mode)."""
+        centre-pixel table, bit 2: pixels of the plain splat mode, bit 3: its
+        verdict entries)."""
         if overflow & 1:
             self.pair_cap = max(self.pair_cap, int(pairs * 1.1) + 4096)
             self.out_cap = max(self.out_cap, int(n_map * 1.1) + 4096)
@@ -430,6 +437,8 @@ class FusedMapPlan:
             self.centre_slots = max(4 * self.centre_slots, 4 * n_map)
         if overflow & 4:
             self.pix_cap = max(self.pix_cap, int(n_pix * 1.1) + 4096)
+        if overflow & 8:
+            self.mask_cap = max(self.mask_cap, int(n_mask * 1.1) + 4096)
 
     def _outputs(self, sl, n_map, n_pix):
         """The sliced outputs of a finished pass: pointers, images, pixels,
@@ -447,12 +456,13 @@ class FusedMapPlan:
         pointers in the plain splat mode)."""
         for _ in range(4):
             sl = self.launch(0)
-            n_map, pairs, overflow, n_seen, n_pix = sl[1].tolist()[:5]
-            self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix)
+            n_map, pairs, overflow, n_seen, n_pix, n_mask, n_chunks = sl[1].tolist()[:7]
+            self.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix,
+                                    verdict_entries=n_mask, chunks=n_chunks)
             if not overflow:
                 self._fit(n_map)
                 return self._outputs(sl, n_map, n_pix)
-            self._grow(n_map, pairs, overflow, n_pix)
+            self._grow(n_map, pairs, overflow, n_pix, n_mask)
         raise L.MvfError("MapImages: buffers still too small after retries")
 
 
@@ -468,11 +478,12 @@ class PendingMap:
         is repeated synchronously with larger buffers."""
         host, event = self._slot[2], self._slot[3]
         event.synchronize()
-        n_map, pairs, overflow, n_seen, n_pix = host.tolist()[:5]
+        n_map, pairs, overflow, n_seen, n_pix, n_mask = host.tolist()[:6]
         if overflow:
-            self.plan._grow(n_map, pairs, overflow, n_pix)
+            self.plan._grow(n_map, pairs, overflow, n_pix, n_mask)
             return self.plan.run()
-        self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix)
+        self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix,
+                                     verdict_entries=n_mask)
         self.plan._fit(n_map)
         return self.plan._outputs(self._slot, n_map, n_pix)
 

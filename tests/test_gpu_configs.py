@@ -330,9 +330,10 @@ def test_non_exact_fused_options_and_overflow():
     assert np.diff(ref["view_pointers"]).max() > 4 and ref["images"].shape[0] > 500
     check_mapping(out.mappings, ref)
     plan = t.prepare_fused(data, images, model, DEV)
-    plan.out_cap, plan.pair_cap, plan.pix_cap = 16, 16, 16
+    plan.out_cap, plan.pair_cap, plan.pix_cap, plan.mask_cap = 16, 16, 16, 8
     res = plan.run()
     assert plan.pix_cap >= ref["pixels"].shape[0] and plan.out_cap >= ref["images"].shape[0]
+    assert plan.mask_cap > ref["pixels"].shape[0] // 16
     from mvfusion.mapping import ImageMapping
     check_mapping(ImageMapping.from_csr_arrays(res[0], res[1], res[2], res[3], res[5]), ref)
 
