@@ -143,12 +143,14 @@ def survey_model_bytes(N, V, W, Hc, M, F, C, depth=False, m_fov=0, Vw=None):
     return b
 
 
-def design_bytes(N, V, M, P, F, C, m_fov, pairs, depth=False, splat=False):
+def design_bytes(N, V, M, P, F, C, m_fov, pairs, depth=False, splat=False, map_px=0, entries=0, chunks=0):
     """HBM bytes each stage of THIS design has to move per sample (inputs read once,
     outputs written once; the z-buffer of a tile lives in LDS and costs none):
     N points, V views, M view-level mapping rows, P mapped pixels, m_fov in-view
     (point, view) pairs, `pairs` (splat, tile) entries, F mapping features, C
-    pixel-feature channels.  16-byte records: key + box of a pair / an entry."""
+    pixel-feature channels.  16-byte records: key + box of a pair / an entry.
+    Plain splat visibility also has: map_px pixels of the views' id maps, `entries`
+    verdict bytes (8 box pixels each) and `chunks` work items of the pixel pass."""
     seen_row = (V + 15) // 16 * 16
     b = {}
     if depth:
@@ -161,7 +163,16 @@ def design_bytes(N, V, M, P, F, C, m_fov, pairs, depth=False, splat=False):
         if not splat:
             b["centre"] = seen_row * N + 12 * N + 8 * M                # flags, cloud, one table slot per seen pair
             b["point_mask"] = seen_row * N + 8 * N + 12 * N + 8 * M + 4 * N * ((V + 31) // 32)
-    b["csr_fill"] = 4 * N * ((V + 31) // 32) + 8 * N + 12 * N + 8 * (N + 1) + M * (8 + 4 * F) + 4 * P
+        else:
+            b["tile_zbuffer"] += 4 * map_px                            # the id maps, written once
+            b["pixel_boxes"] = 16 * m_fov + M + 16 * M + 16 * chunks   # records and flags in, pair records and chunks out
+            b["pixel_mark"] = 4 * map_px + 16 * M + entries            # id maps and pair records in, verdict bytes out (cleared first)
+            b["pixel_scan"] = 2 * entries + entries // 2               # verdicts in twice, one count per 8 entries out
+            b["pixel_count"] = 16 * m_fov + M + 16 * M + 8 * M + 4 * M
+            b["point_mask"] = seen_row * N + 8 * N + 4 * M + 4 * N * ((V + 31) // 32)
+            b["pixel_fill"] = 16 * chunks + 16 * M + entries + entries // 2 + 4 * P
+    b["csr_fill"] = 4 * N * ((V + 31) // 32) + 8 * N + 12 * N + 8 * (N + 1) + M * (8 + 4 * F) + (
+        (8 + 16 + 16) * M if splat else 4 * P)         # plain splat: view pointers out, pair records in and out
     # the fused two-level pool: pixel features read once, max and mean view pools written once
     b["pools"] = 4 * C * P + 2 * 4 * C * N + 8 * (N + 1) + 8 * (M + 1)
     b["total"] = sum(b.values())
@@ -612,7 +623,8 @@ def run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=True):
             m_fov = pairs                   # (a lower bound of the in-view pairs is their tile entries)
     else:
         m_fov = M                           # the pairs that pass the depth test are a lower bound of those tested
-    D = design_bytes(N, V, M, Pn, plan.F, C_feat, m_fov, pairs, depth=depth, splat=splat)
+    D = design_bytes(N, V, M, Pn, plan.F, C_feat, m_fov, pairs, depth=depth, splat=splat, map_px=V * W * H,
+                     entries=plan.last_counts.get("verdict_entries", 0), chunks=plan.last_counts.get("chunks", 0))
     S_ = survey_model_bytes(N, V, W, H, Pn, plan.F, C_feat, depth=depth, m_fov=m_fov, Vw=M)
     ms_step = elapsed / args.steps * 1e3
     tcfg = cfg if (exact or depth) else cfg + "_nonexact"      # key of the PMC traffic table

@@ -279,14 +279,15 @@ int mvf_map_images_exact_batch(
  * pix_capacity; features [Vw][F] = mean over the view's pixels.
  * mask_capacity: room of the pass's verdict buffer, in entries of 8 pixels:
  * every (point, view) pair that wins a pixel takes one entry per column of
- * its splat box and group of 8 image rows (8g .. 8g+7) the box reaches
- * (0 = a quarter of an entry per pixel of the views; the workspace size
- * follows it, so pass the same value to both functions).
+ * its splat box and group of 8 image rows (8g .. 8g+7) the box reaches,
+ * rounded up to a multiple of 8 (0 = half an entry per pixel of the views;
+ * the workspace size follows it, so pass the same value to both functions).
  * counters (8 words): [0] <- Vw, [1] <- (splat, tile) pairs needed,
  * [2] <- overflow flags (bit 0: pair_capacity or out_capacity, bit 2:
  * pix_capacity, bit 3: mask_capacity), [3] <- views with at least one
- * mapping, [4] <- P, [5] <- verdict entries needed.  After an overflow the
- * outputs are incomplete: call again with the capacities the counters name.
+ * mapping, [4] <- P, [5] <- verdict entries needed, [6] <- work items of the
+ * pixel pass (informational).  After an overflow the outputs are incomplete:
+ * call again with the capacities the counters name.
  * ---------------------------------------------------------------------- */
 size_t mvf_map_images_splat_workspace_bytes(
     int64_t n, int32_t V, int32_t W, int32_t H, int64_t num_points, int64_t pair_capacity,

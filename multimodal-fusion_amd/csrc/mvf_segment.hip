@@ -103,12 +103,18 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
 // max / min over long segments (many rows per segment, e.g. the pixels of a
 // splat): the serial walk above keeps one thread on a segment and is bound by
 // its chain of loads.  Here a wave takes a segment: lane = (row group, channel)
-// with 64 >> cp_log row groups of 1 << cp_log >= min(C, 64) channels, four steps
-// of rows in flight, and a final combine across the row groups.  Ties (+0.0 /
+// with 64 >> cp_log row groups of 1 << cp_log >= min(C, 64) channels,
+// SEG_LONG_LOADS steps of rows in flight, and a final combine across the row
+// groups.  Ties (+0.0 /
 // -0.0 compare equal) go to the first row, as in the in-order fold, and a NaN
 // counts where that fold counts it (it sticks when it is the segment's first
 // row and is passed over anywhere else: every comparison with it is false), so
 // the result is bit-identical to segment_csr_kernel's.
+#ifndef MVF_SEG_LONG_LOADS
+#define MVF_SEG_LONG_LOADS 16
+#endif
+constexpr int SEG_LONG_LOADS = MVF_SEG_LONG_LOADS;       // rows a lane has in flight
+
 template <int MODE>
 __global__ __launch_bounds__(256) void segment_long_kernel(
     const float *__restrict__ src, int C, int cp_log, const i64 *__restrict__ ptr, i64 nseg,
@@ -128,16 +134,16 @@ __global__ __launch_bounds__(256) void segment_long_kernel(
         unsigned at = 0xffffffffu;                    // row (relative to a) the value comes from
         const float *q = src + (size_t)a * C + ch;
         const unsigned n = (unsigned)(b - a);
-        for (unsigned r = (unsigned)ro; r < n && live; r += 4u * (unsigned)rp) {
-            float x[4];
-            bool ok[4];
+        for (unsigned r = (unsigned)ro; r < n && live; r += (unsigned)(SEG_LONG_LOADS * rp)) {
+            float x[SEG_LONG_LOADS];
+            bool ok[SEG_LONG_LOADS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SEG_LONG_LOADS; ++k) {
                 ok[k] = r + (unsigned)(k * rp) < n;
                 x[k] = ok[k] ? q[(size_t)(r + (unsigned)(k * rp)) * C] : 0.f;
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < SEG_LONG_LOADS; ++k) {
                 const unsigned rk = r + (unsigned)(k * rp);
                 // a lane starts from its first number (or from row 0, whatever it holds)
                 const bool start = at == 0xffffffffu && (x[k] == x[k] || rk == 0u);

@@ -478,12 +478,12 @@ class PendingMap:
         is repeated synchronously with larger buffers."""
         host, event = self._slot[2], self._slot[3]
         event.synchronize()
-        n_map, pairs, overflow, n_seen, n_pix, n_mask = host.tolist()[:6]
+        n_map, pairs, overflow, n_seen, n_pix, n_mask, n_chunks = host.tolist()[:7]
         if overflow:
             self.plan._grow(n_map, pairs, overflow, n_pix, n_mask)
             return self.plan.run()
         self.plan.last_counts = dict(mappings=n_map, pairs=pairs, seen_views=n_seen, pixels=n_pix,
-                                     verdict_entries=n_mask)
+                                     verdict_entries=n_mask, chunks=n_chunks)
         self.plan._fit(n_map)
         return self.plan._outputs(self._slot, n_map, n_pix)
 

@@ -20,15 +20,18 @@ EXACT = {"bin_count_kernel": 1, "tile_scan_kernel": 1, "bin_fill_kernel": 1, "ti
          "mi_centre_kernel": 1, "mi_point_mask_kernel": 1, "mi_fill_kernel": 1, "two_level_pool_kernel": 1}
 DEPTH = {"mi_point_mask_kernel": 1, "mi_fill_kernel": 1, "two_level_pool_kernel": 1}
 SPLAT = {"bin_count_kernel": 1, "tile_scan_kernel": 1, "bin_fill_kernel": 1, "tile_zbuffer_kernel": 1,
-         "ne_scan_kernel": 2, "ne_point_kernel": 1, "ne_fill_kernel": 1, "segment_long_kernel": 1,
-         "two_level_pool_kernel": 1}
+         "ne_box_kernel": 1, "ne_mark_kernel": 1, "ne_bits_reduce_kernel": 1, "scan_spine_kernel": 1,
+         "ne_bits_apply_kernel": 1, "ne_count_kernel": 1, "ne_point_kernel": 1, "ne_fill_kernel": 1,
+         "ne_emit_kernel": 1, "segment_long_kernel": 1, "two_level_pool_kernel": 1}
 PIPELINE = {"c1": EXACT, "c2": EXACT, "c4": EXACT, "c5": DEPTH, "c2_nonexact": SPLAT}
 
 STAGE = {"bin_count_kernel": "bin_count", "tile_scan_kernel": "tile_scan", "bin_fill_kernel": "bin_fill",
          "tile_zbuffer_kernel": "tile_zbuffer", "mi_centre_kernel": "centre",
          "mi_point_mask_kernel": "point_mask", "mi_fill_kernel": "csr_fill",
-         "two_level_pool_kernel": "pools", "ne_scan_kernel": "pixel_scan", "ne_point_kernel": "point_mask",
-         "ne_fill_kernel": "csr_fill"}
+         "two_level_pool_kernel": "pools", "ne_point_kernel": "point_mask", "ne_fill_kernel": "csr_fill",
+         "ne_box_kernel": "pixel_boxes", "ne_mark_kernel": "pixel_mark", "ne_count_kernel": "pixel_count",
+         "ne_emit_kernel": "pixel_fill", "segment_long_kernel": "pools", "ne_bits_reduce_kernel": "pixel_scan",
+         "ne_bits_apply_kernel": "pixel_scan"}
 
 
 def per_kernel(d, counter):
@@ -50,7 +53,7 @@ for k in sorted(set(fetch) | set(write)):
     f = 2.0 * sum(fetch[k]) / max(len(fetch[k]), 1)
     w = sum(write[k]) / max(len(write[k]), 1)
     detail[k] = dict(fetch_bytes_x2=f, write_bytes=w, launches_sampled=len(fetch[k]))
-    out[STAGE.get(k, k)] = f + w
+    out[STAGE.get(k, k)] = out.get(STAGE.get(k, k), 0.0) + f + w      # (a stage may be several kernels)
 # one QKVBimodalCSRPool.forward = all launches between two score launches
 nfwd = len(fetch.get("attention_scores_kernel", []))
 total = sum(2.0 * sum(fetch[k]) + sum(write[k]) for k in set(fetch) | set(write))
