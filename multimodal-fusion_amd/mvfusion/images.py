@@ -23,7 +23,7 @@ class SameSettingImageData:
                  proj_upscale=2, downscale=1, crop_size=None, crop_offsets=None,
                  x=None, mappings=None, mask=None, visibility=None, opk=None,
                  xi=None, k1=None, k2=None, gamma1=None, gamma2=None, u0=None, v0=None,
-                 **kwargs):
+                 rollings=None, **kwargs):
         self.pos = pos.double()
         self.opk = opk.double() if opk is not None else None
         self.xi, self.k1, self.k2 = xi, k1, k2
@@ -39,6 +39,9 @@ class SameSettingImageData:
         self.crop_size = tuple(crop_size) if crop_size is not None else self.ref_size
         self.crop_offsets = crop_offsets if crop_offsets is not None \
             else torch.zeros((n, 2), dtype=torch.int64, device=self.pos.device)
+        # horizontal roll of every (circular) image with respect to ref_size, int64 [V]
+        self.rollings = rollings.long() if rollings is not None \
+            else torch.zeros(n, dtype=torch.int64, device=self.pos.device)
         self._x = None
         self.x = x
         self.mappings = mappings
@@ -95,6 +98,27 @@ class SameSettingImageData:
             self.mappings = self.mappings.crop(crop_size, crop_offsets)
         return self
 
+    def update_rollings(self, rollings):
+        """Roll the feature maps and the mappings along the width, for images
+        with a circular representation (first and last column adjacent);
+        ``rollings`` [V] int64 is kept with respect to ``ref_size``.  Not after a
+        crop along the width or a resize (core/multimodal/image.py:578-627).
+        In place."""
+        who = "CenterRoll cannot operate if images and mappings underwent prior cropping or resizing."
+        assert self.ref_size[0] == self.img_size[0], who
+        assert self.crop_size is None or tuple(self.crop_size) == tuple(self.ref_size), who
+        assert self.downscale is None or self.downscale == 1, who
+        self.rollings = rollings.long().to(self.device)
+        if self._x is not None:
+            self._x = torch.stack([torch.roll(im, int(r), dims=-1) for im, r in zip(self._x, self.rollings)])
+        if self.mappings is not None:
+            m = self.mappings
+            per_pixel = self.rollings.to(m.images.device)[m.images].repeat_interleave(
+                m.values[1].pointers[1:] - m.values[1].pointers[:-1])
+            w = (m.pixels[:, 0].long() + per_pixel) % self.ref_size[0]
+            m.pixels[:, 0] = w.to(self.pixel_dtype)
+        return self
+
     # the reference exposes these as computed properties
     @property
     def num_views(self):
@@ -107,7 +131,7 @@ class SameSettingImageData:
     _fisheye_keys = ('xi', 'k1', 'k2', 'gamma1', 'gamma2', 'u0', 'v0')
     _pinhole_keys = ('fx', 'fy', 'mx', 'my')
     # per-view attributes (concatenated by a batch) / attributes all views share
-    _torch_keys = ('pos', 'opk', 'extrinsic', 'crop_offsets') + _pinhole_keys + _fisheye_keys
+    _torch_keys = ('pos', 'opk', 'extrinsic', 'crop_offsets', 'rollings') + _pinhole_keys + _fisheye_keys
     _shared_keys = ('ref_size', 'proj_upscale', 'downscale', 'crop_size', 'mask', 'visibility')
 
     def to_dict(self):
@@ -208,7 +232,7 @@ class SameSettingImageData:
             proj_upscale=copy.deepcopy(self.proj_upscale),
             downscale=copy.deepcopy(self.downscale),
             crop_size=copy.deepcopy(self.crop_size), crop_offsets=sel(self.crop_offsets),
-            x=sel(self.x),
+            rollings=sel(self.rollings), x=sel(self.x),
             mappings=self.mappings.select_images(idx) if self.mappings is not None else None,
             mask=self.mask.clone() if self.mask is not None else None,
             visibility=copy.deepcopy(self.visibility), opk=sel(self.opk),
@@ -375,6 +399,10 @@ class ImageData:
     def num_points(self):
         """Number of points the mappings refer to (0 when there is no image)."""
         return self._list[0].num_points if len(self._list) > 0 else 0
+
+    @property
+    def num_views(self):
+        return sum(im.num_views for im in self._list)
 
     @staticmethod
     def get_batch_type():

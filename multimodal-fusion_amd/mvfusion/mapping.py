@@ -55,8 +55,14 @@ def lexargunique(*cols):
     return order[first]
 
 
-def lexunique(col):
-    return torch.unique(col, sorted=True)
+def lexunique(*cols):
+    """Distinct rows of the columns in lexicographic order: one tensor for one
+    column, a list of columns otherwise (cpu_lex_op 'unique',
+    utils/multimodal.py:313-317)."""
+    if len(cols) == 1:
+        return torch.unique(cols[0], sorted=True)
+    first = lexargunique(*cols)
+    return [c[first] for c in cols]
 
 
 def _csr_from_dense_rows(point_ids, image_ids, pixels, features, num_points, num_images,

@@ -1133,6 +1133,111 @@ class PickImagesFromMappingArea(ImageTransform):
         return data, images[ranked]
 
 
+class PickImagesFromMemoryCredit(ImageTransform):
+    """Draws images from an ``ImageData`` until a budget of pixels (``credit``, or
+    ``n_img`` images of ``img_size``) is spent.  An image is drawn with a
+    probability proportional to its pixel area relative to the largest
+    candidate plus, with ``k_coverage`` > 0, ``k_coverage`` times the share of
+    still unseen points it would add; candidates larger than the remaining
+    credit leave the draw (core/data_transform/multimodal/image.py:765-874).
+    Draws come from ``np.random`` in the reference's order, one
+    ``np.random.choice`` per picked image."""
+
+    _PROCESS_IMAGE_DATA = True
+
+    def __init__(self, credit=None, img_size=[], k_coverage=0, n_img=0):
+        if credit is not None:
+            self.credit = credit
+        elif len(img_size) == 2 and n_img > 0:
+            self.credit = img_size[0] * img_size[1] * n_img
+        else:
+            raise ValueError("Either credit or img_size and n_img must be provided.")
+        self.use_coverage = k_coverage > 0
+        self.k_coverage = k_coverage
+
+    def _process(self, data, images):
+        if images.num_views == 0:
+            return data, images
+        # candidates in (setting, view) order: owner setting, view, pixel area
+        owner = [(i, j) for i, im in enumerate(images) for j in range(im.num_views)]
+        area = [images[i].img_size[0] * images[i].img_size[1] for i, _ in owner]
+        unseen = None
+        if self.use_coverage:
+            # points every candidate sees, as rows of a boolean matrix
+            sees = torch.zeros(images.num_views, data.num_nodes, dtype=torch.bool)
+            first = 0
+            for im in images:
+                m = im.mappings
+                rows = (m.images + first).cpu()
+                pts = m.points.repeat_interleave(m.pointers[1:] - m.pointers[:-1]).cpu()
+                sees[rows, pts] = True
+                first += im.num_views
+            unseen = [r.numpy() for r in sees]
+        credit = self.credit
+        assert credit > 0 and credit >= min(area), \
+            f"Insufficient credit={credit} to pick any of the provided images with min_size={min(area)}."
+        picked = [[] for _ in range(len(images))]
+        while credit > 0 and len(owner) > 0 and credit >= min(area):
+            fits = [k for k, a in enumerate(area) if a <= credit]
+            owner = [owner[k] for k in fits]
+            area = [area[k] for k in fits]
+            if unseen is not None:
+                unseen = [unseen[k] for k in fits]
+                gain = np.array([u.sum() for u in unseen])
+                gain = self.k_coverage * gain / (gain.max() + 1)
+            else:
+                gain = np.zeros(len(owner))
+            weights = np.array(area) / np.array(area).max() + gain
+            k = np.random.choice(np.arange(weights.shape[0]), p=weights / weights.sum())
+            i, j = owner.pop(k)
+            credit -= area.pop(k)
+            picked[i].append(j)
+            if unseen is not None:
+                new = unseen.pop(k)
+                unseen = [np.logical_and(u, ~new) for u in unseen]
+        return data, ImageData([im[torch.LongTensor(idx)] for im, idx in zip(images, picked) if len(idx) > 0])
+
+
+class CenterRoll(ImageTransform):
+    """Rolls spherical images (and their mappings) along the width so that the
+    mapped pixels sit as close to the centre column as possible: of
+    ``angular_res`` evenly spaced rolls every image takes the one that
+    minimises (span of its mapped columns + distance of their middle from the
+    centre), columns measured on a 256-step circle
+    (core/data_transform/multimodal/image.py:962-1037)."""
+
+    def __init__(self, angular_res=16):
+        assert isinstance(angular_res, int)
+        assert angular_res <= 256
+        self.angular_res = angular_res
+
+    def _process(self, data, images):
+        who = f"{self.__class__.__name__} cannot operate if images and mappings underwent prior cropping or resizing."
+        assert images.mappings is not None, "No mappings found in images."
+        assert images.ref_size[0] == images.img_size[0], who
+        assert images.crop_size is None or images.crop_size[0] == images.ref_size[0], who
+        assert images.downscale is None or images.downscale == 1, who
+        m = images.mappings
+        if m.images.shape[0] == 0:
+            return data, images
+        # mapped columns on the 256-step circle, one row per distinct (image, column)
+        img = m.images.repeat_interleave(m.values[1].pointers[1:] - m.values[1].pointers[:-1])
+        col = (m.pixels[:, 0].float() * 256 / images.ref_size[0]).long()
+        img, col = lexunique(img, col)
+        rolls = torch.arange(0, 256, int(256 / self.angular_res), device=col.device)
+        rolled = (col.view(-1, 1) + rolls.view(1, -1)) % 256           # uint8 wrap-around of the reference
+        index = img.view(-1, 1).expand_as(rolled)
+        shape = (images.num_views, rolls.shape[0])
+        lo = torch.full(shape, 255, dtype=torch.int64, device=col.device).scatter_reduce_(0, index, rolled, 'amin')
+        hi = torch.zeros(shape, dtype=torch.int64, device=col.device).scatter_reduce_(0, index, rolled, 'amax')
+        off_centre = ((hi.float() + lo) / 2. - 128).abs().int()
+        cost = (hi - lo).int() + off_centre
+        best = cost.min(dim=1).indices                                   # (an image without mappings keeps roll 0)
+        rollings = (rolls[best] / 256. * images.ref_size[0]).long()
+        images.update_rollings(rollings)
+        return data, images
+
+
 class PickMappingsFromMappingFeatures(ImageTransform):
     """Drops the views whose mapping features fall outside per-feature lower /
     upper bounds, both exclusive (core/data_transform/multimodal/image.py:877-931)."""

@@ -885,6 +885,67 @@ def gen_crop_groups():
     save("crop_groups", **arrs)
 
 
+def gen_roll_and_credit():
+    """CenterRoll with SameSettingImageData.update_rollings underneath, and
+    PickImagesFromMemoryCredit with and without the coverage weights
+    (core/data_transform/multimodal/image.py:765-874, 962-1037;
+    core/multimodal/image.py:578-627) on spherical images whose mapped columns
+    sit in different places, some across the seam."""
+    image, tr = ref["image"], ref["transforms"]
+    rng = np.random.default_rng(101)
+    n, n_img, W, H = 400, 6, 512, 256
+    # per image: centre column and half width of the mapped band (columns wrap around)
+    bands = [(20, 60), (256, 40), (500, 90), (130, 200), (384, 10), (0, 255)]
+    pid, iid, pix = [], [], []
+    for i, (c, hw) in enumerate(bands):
+        pts = np.sort(rng.permutation(n)[:rng.integers(30, 150)])
+        pid.append(pts)
+        iid.append(np.full(pts.shape[0], i))
+        cols = (c + rng.integers(-hw, hw + 1, pts.shape[0])) % W
+        pix.append(np.stack([cols, rng.integers(0, H, pts.shape[0])], 1))
+    pid, iid = np.concatenate(pid).astype(np.int64), np.concatenate(iid).astype(np.int64)
+    pix = np.concatenate(pix).astype(np.int16)
+    feat = rng.random((pid.shape[0], 2)).astype(np.float32)
+    x = np.arange(n_img * 2 * H * W, dtype=np.float32).reshape(n_img, 2, H, W) % 1021
+    pos_img = rng.random((n_img, 3))
+
+    def fresh(with_x=True, views=None, size=(W, H)):
+        sel = np.arange(n_img) if views is None else np.asarray(views)
+        keep = np.isin(iid, sel)
+        new_id = np.searchsorted(sel, iid[keep])
+        px = pix[keep].copy()
+        px[:, 0] %= size[0]
+        px[:, 1] %= size[1]
+        m = image.ImageMapping.from_dense(T(pid[keep]), T(new_id), T(px), T(feat[keep]), num_points=n)
+        return image.SameSettingImageData(
+            path=np.array([f"s{size[0]}_v{i}" for i in sel], dtype='O'), pos=T(pos_img[sel]),
+            ref_size=size, proj_upscale=1, downscale=1, mappings=m,
+            x=T(x[sel][:, :, :size[1], :size[0]].copy()) if with_x else None)
+
+    arrs = dict(pos_img=pos_img, size=np.array([W, H]), n_img=n_img, x_mod=1021)
+    arrs.update(mapping_arrays(fresh().mappings, "in_"))
+    data = _refshim.Data(pos=T(rng.random((n, 3)).astype(np.float32)))
+    for res in (16, 4, 256):
+        _, out = tr.CenterRoll(angular_res=res)(data, fresh())
+        t = f"roll{res}"
+        arrs[t + "_rollings"] = out.rollings.numpy()
+        arrs[t + "_x_head"] = out.x[:, 0, 0, :8].numpy()
+        arrs[t + "_x_sum_cols"] = out.x.double().sum(dim=(1, 2)).numpy()[:, ::37]
+        arrs.update(mapping_arrays(out.mappings, t + "_"))
+    # memory credit: two settings (full and half size images), seeded draws
+    for tag, kw, seed in (("credit", dict(credit=3 * W * H), 5),
+                          ("credit_cov", dict(img_size=[W, H], n_img=2, k_coverage=2), 6),
+                          ("credit_small", dict(credit=W * H // 4 + 5, k_coverage=0.5), 7)):
+        ims = image.ImageData([fresh(False, [0, 2, 3, 5]), fresh(False, [1, 4], size=(W // 2, H // 2))])
+        np.random.seed(seed)
+        _, out = tr.PickImagesFromMemoryCredit(**kw)(data, ims)
+        arrs[tag + "_n"] = len(out)
+        for j, im in enumerate(out):
+            arrs[f"{tag}_{j}_path"] = np.array([str(p) for p in im.path])
+            arrs.update(mapping_arrays(im.mappings, f"{tag}_{j}_"))
+    save("roll_and_credit", **arrs)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -938,6 +999,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping", "crop_groups"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping", "crop_groups", "roll_and_credit"]
     for w in which:
         globals()["gen_" + w]()

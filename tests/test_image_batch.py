@@ -209,3 +209,73 @@ def test_bounding_boxes_and_feature_thresholds(golden):
     _, im = JitterMappingFeatures(sigma=0.5, clip=0.03)(data, im)
     d = (im.mappings.features - before).abs()
     assert 0 < float(d.max()) <= 0.03 + 1e-7
+
+
+def _roll_sample(g, with_x=True, views=None, size=None):
+    """The spherical sample of roll_and_credit.npz, or the views `views` of it at image size `size`."""
+    n_img, (W, H) = int(g["n_img"]), (int(v) for v in g["size"])
+    size = (W, H) if size is None else size
+    sel = np.arange(n_img) if views is None else np.asarray(views)
+    m = mapping(g, "in_")
+    if views is not None:
+        m = m.select_images(torch.as_tensor(sel, device=DEV))
+    px = m.pixels.clone()                  # (update_rollings edits the pixels in place)
+    px[:, 0] %= size[0]
+    px[:, 1] %= size[1]
+    m.pixels = px
+    x = None
+    if with_x:
+        x = (torch.arange(n_img * 2 * H * W, dtype=torch.float32, device=DEV).view(n_img, 2, H, W)
+             % int(g["x_mod"]))[torch.as_tensor(sel, device=DEV)][:, :, :size[1], :size[0]].contiguous()
+    return SameSettingImageData(
+        path=[f"s{size[0]}_v{i}" for i in sel], pos=T(g["pos_img"][sel]), ref_size=size,
+        proj_upscale=1, downscale=1, mappings=m, x=x)
+
+
+def test_center_roll(golden):
+    """CenterRoll + SameSettingImageData.update_rollings against the reference's
+    own run: rollings, rolled mappings (width coordinates modulo the image
+    width), rolled feature maps; rollings follow an image through indexing and
+    batching."""
+    from mvfusion.transforms import CenterRoll
+    g = golden("roll_and_credit")
+    data = _Data(pos=torch.zeros(3, 3, device=DEV))
+    for res in (16, 4, 256):
+        _, out = CenterRoll(angular_res=res)(data, _roll_sample(g))
+        t = f"roll{res}"
+        assert np.array_equal(N(out.rollings), g[t + "_rollings"]) and out.rollings.dtype == torch.int64
+        same(out.mappings, g, t + "_")
+        assert np.array_equal(N(out.x[:, 0, 0, :8]), g[t + "_x_head"])
+        assert np.array_equal(N(out.x.double().sum(dim=(1, 2)))[:, ::37], g[t + "_x_sum_cols"])
+    assert np.array_equal(N(out[torch.tensor([4, 1])].rollings), g["roll256_rollings"][[4, 1]])
+    batch = SameSettingImageBatch.from_data_list([out[torch.tensor([0, 1])], out[torch.tensor([5])]])
+    assert np.array_equal(N(batch.rollings), g["roll256_rollings"][[0, 1, 5]])
+    # not after a crop along the width
+    im = _roll_sample(g)
+    im.crop_size = (256, 256)
+    with pytest.raises(AssertionError):
+        CenterRoll()(data, im)
+
+
+def test_pick_images_from_memory_credit(golden):
+    """PickImagesFromMemoryCredit on an ImageData of two settings, with the
+    reference's seeded draws: same images in the same order, same mappings."""
+    from mvfusion.transforms import PickImagesFromMemoryCredit
+    g = golden("roll_and_credit")
+    W, H = (int(v) for v in g["size"])
+    n = mapping(g, "in_").num_groups
+    data = _Data(pos=torch.zeros(n, 3, device=DEV), num_nodes=n)
+    for tag, kw, seed in (("credit", dict(credit=3 * W * H), 5),
+                          ("credit_cov", dict(img_size=[W, H], n_img=2, k_coverage=2), 6),
+                          ("credit_small", dict(credit=W * H // 4 + 5, k_coverage=0.5), 7)):
+        ims = ImageData([_roll_sample(g, False, [0, 2, 3, 5]), _roll_sample(g, False, [1, 4], size=(W // 2, H // 2))])
+        np.random.seed(seed)
+        _, out = PickImagesFromMemoryCredit(**kw)(data, ims)
+        assert len(out) == int(g[tag + "_n"]), tag
+        for j, im in enumerate(out):
+            assert [str(p) for p in im.path] == [str(p) for p in g[f"{tag}_{j}_path"]], tag
+            same(im.mappings, g, f"{tag}_{j}_")
+    with pytest.raises(ValueError):
+        PickImagesFromMemoryCredit()
+    with pytest.raises(AssertionError):
+        PickImagesFromMemoryCredit(credit=10)(data, ImageData([_roll_sample(g, False)]))
