@@ -1325,7 +1325,8 @@ constexpr int NE_BOX_GROUP = 8;
 __global__ __launch_bounds__(256) void ne_box_kernel(
     const TileEntry *__restrict__ staged, const unsigned *__restrict__ staged_count, unsigned staged_blocks,
     const uint8_t *__restrict__ seen, i64 seen_stride, i64 n, NePair *__restrict__ pairs,
-    uint4 *__restrict__ chunks, i64 mask_capacity, u64 *__restrict__ cursor, i64 *__restrict__ counters)
+    uint4 *__restrict__ chunks, i64 chunk_capacity, i64 mask_capacity, u64 *__restrict__ cursor,
+    i64 *__restrict__ counters)
 {
     __shared__ u64 s_base[2];
     const int tid = threadIdx.x, v = blockIdx.y;
@@ -1384,9 +1385,12 @@ __global__ __launch_bounds__(256) void ne_box_kernel(
                                  (items[g] ? ne_groups(e[g].ya, e[g].yb) : 0u) << 16);
         if (first[g] == NE_NO_MASKS) continue;
         const unsigned words = items[g] >> 3;
-        for (unsigned w = 0; w < words; w += NE_CHUNK)
-            chunks[at++] = make_uint4((unsigned)pair, (first[g] >> 3) + w,
-                                      words - w < (unsigned)NE_CHUNK ? words - w : (unsigned)NE_CHUNK, (unsigned)v);
+        // (the list has room for one chunk per (splat, tile) entry the call was sized for -- a seen
+        // pair has at least one -- plus the full chunks: it only runs out when those did)
+        for (unsigned w = 0; w < words; w += NE_CHUNK, ++at)
+            if (at < (u64)chunk_capacity)
+                chunks[at] = make_uint4((unsigned)pair, (first[g] >> 3) + w,
+                                        words - w < (unsigned)NE_CHUNK ? words - w : (unsigned)NE_CHUNK, (unsigned)v);
     }
     if (any_over && tid == 0) atomicOr((unsigned long long *)&counters[2], 8ull);
 }
@@ -1544,10 +1548,11 @@ constexpr int NE_EMIT_SLOTS = 1024;          // pixels of a wave staged at a tim
 __global__ __launch_bounds__(256) void ne_emit_kernel(
     const uint4 *__restrict__ chunks, const u64 *__restrict__ cursor, const NePair *__restrict__ pairs,
     const u64 *__restrict__ verdicts, const unsigned *__restrict__ bits_before,
-    const mvf_view *__restrict__ views, int crop_top, unsigned *__restrict__ pixels, i64 pix_capacity)
+    const mvf_view *__restrict__ views, int crop_top, unsigned *__restrict__ pixels, i64 pix_capacity,
+    i64 chunk_capacity)
 {
     __shared__ unsigned s_pix[4][NE_EMIT_SLOTS + 64];     // + one spare slot per lane
-    const u64 nc = cursor[1];
+    const u64 nc = cursor[1] < (u64)chunk_capacity ? cursor[1] : (u64)chunk_capacity;
     const unsigned n_chunks = nc < 0xffffffffull ? (unsigned)nc : 0xffffffffu;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned sub = lane / NE_CHUNK, wl = lane % NE_CHUNK;
@@ -2143,6 +2148,7 @@ struct MapWorkspace {
     i64 *block_pix;
     uint8_t *verdicts;
     uint4 *ne_pairs, *ne_chunks;
+    i64 chunk_capacity;
     i64 mask_capacity;
     // Vw: views a point can meet (V, or the largest sample of a batched call)
     bool carve(void *workspace, size_t workspace_bytes, i64 n, int V, i64 tiles, i64 num_points,
@@ -2174,7 +2180,7 @@ struct MapWorkspace {
         block_pix = nullptr;
         verdicts = nullptr;
         ne_pairs = ne_chunks = nullptr;
-        mask_capacity = 0;
+        mask_capacity = chunk_capacity = 0;
         if (map_pixels > 0) {
             idmap = ar.take<unsigned>((size_t)map_pixels);
             cnt = ar.take<unsigned>((size_t)n * V);
@@ -2184,8 +2190,10 @@ struct MapWorkspace {
             bits_before = ar.take<unsigned>((size_t)mask_capacity / 8 + 16);
             bits_blocks = ar.take<unsigned>((size_t)cdiv(mask_capacity / 8 + 1, 2048) + 1);
             ne_pairs = ar.take<uint4>((size_t)n * V);
-            // every pair at least one chunk, and one per NE_CHUNK words (128 entries)
-            ne_chunks = ar.take<uint4>((size_t)n * V + (size_t)mask_capacity / 128 + 1);
+            // a seen pair has at least one chunk and at least one (splat, tile) entry; then one
+            // chunk per NE_CHUNK words (128 entries)
+            chunk_capacity = pair_capacity + mask_capacity / 128 + 1;
+            ne_chunks = ar.take<uint4>((size_t)chunk_capacity);
         }
         used = ar.off;
         return ar.ok();
@@ -2542,8 +2550,8 @@ static int map_images_splat_impl(
     const u64 *verdicts = (const u64 *)ws.verdicts;
     const NeImage img{ws.idmap, P.W, Hc, P.crop_top, crop_w, crop_h, (i64)n};
     hipLaunchKernelGGL(ne_box_kernel, dim3(cdiv(grid_nv.x, NE_BOX_GROUP), V), block, 0, st, ws.staged, ws.staged_count,
-                       grid_nv.x, cseen, ws.seen_stride, (i64)n, ws.ne_pairs, ws.ne_chunks, ws.mask_capacity, cursor,
-                       (i64 *)counters);
+                       grid_nv.x, cseen, ws.seen_stride, (i64)n, ws.ne_pairs, ws.ne_chunks, ws.chunk_capacity,
+                       ws.mask_capacity, cursor, (i64 *)counters);
     prof_mark("pixel_boxes", st);
     hipLaunchKernelGGL(ne_mark_kernel, dim3((unsigned)(tiles * NE_MARK_BLOCKS)), block, 0, st, ws.descs, n_desc, img,
                        views, (const NePair *)ws.ne_pairs, ws.verdicts);
@@ -2572,7 +2580,7 @@ static int map_images_splat_impl(
     // a fixed grid that fills the device; the waves stride over the chunks
     hipLaunchKernelGGL(ne_emit_kernel, dim3(256 * 8), block, 0, st, (const uint4 *)ws.ne_chunks, cursor,
                        (const NePair *)ws.ne_pairs, verdicts, (const unsigned *)ws.bits_before, views, P.crop_top,
-                       (unsigned *)pixels, (i64)pix_capacity);
+                       (unsigned *)pixels, (i64)pix_capacity, ws.chunk_capacity);
     prof_mark("pixel_fill", st);
     MVF_LAUNCH_CHECK();
     return MVF_OK;
