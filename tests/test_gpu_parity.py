@@ -312,13 +312,22 @@ def test_fused_plans_on_concurrent_streams():
     torch.cuda.synchronize()
 
 
-def test_map_images_no_mapping_raises():
+@pytest.mark.parametrize("exact", [True, False])
+def test_map_images_no_mapping_raises(exact):
+    """No point in range of any camera: the fused passes (exact and plain splat: no
+    tile, no pair, no pixel) come back empty and MapImages raises as the reference does."""
     from mvfusion.transforms import MapImages
     sc = S.make_scene("c1", seed=3, n_points=2000, n_views=2)
     xyz = sc["xyz"] + np.float32(500.0)          # far away from every camera
     data, images = make_inputs(xyz, np.arange(2000), sc, sc["img_size"], attrs=False)
-    t = MapImages(method="SplattingVisibility", cylinder=True, exact=True,
-                  point_order="index", **VIS)
+    t = MapImages(method="SplattingVisibility", cylinder=True, point_order="index",
+                  **dict(VIS, exact=exact))
+    model = t._settle(data, images)
+    assert t._fusable(images, model)
+    plan = t.prepare_fused(data, images, model, torch.device("cuda", 0))
+    res = plan.run()
+    assert plan.last_counts["mappings"] == 0 and plan.last_counts["pixels"] == 0
+    assert int(res[0][-1]) == 0 and res[1].shape[0] == 0 and res[2].shape[0] == 0
     with pytest.raises(ValueError):
         t(data, images)
 
