@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(256) void ne_emit_kernel(
     const mvf_view *__restrict__ views, int crop_top, unsigned *__restrict__ pixels, i64 pix_capacity,
     i64 chunk_capacity)
 {
-    __shared__ unsigned s_pix[4][NE_EMIT_SLOTS + 64];     // + one spare slot per lane
+    __shared__ unsigned s_pix[4][NE_EMIT_SLOTS];
     const u64 nc = cursor[1] < (u64)chunk_capacity ? cursor[1] : (u64)chunk_capacity;
     const unsigned n_chunks = nc < 0xffffffffull ? (unsigned)nc : 0xffffffffu;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1607,10 +1607,8 @@ __global__ __launch_bounds__(256) void ne_emit_kernel(
                 if (__ballot(byte != 0u)) {
 #pragma unroll
                     for (unsigned b = 0; b < 8u; ++b) {
-                        // (a store per row and lane, to the lane's spare slot where the bit is clear
-                        // or the pixel is outside the window: no branch)
                         const unsigned set = (byte >> b) & 1u;
-                        s_pix[wave][set && slot < (unsigned)NE_EMIT_SLOTS ? slot : NE_EMIT_SLOTS + lane] = xy + (b << 16);
+                        if (set && slot < (unsigned)NE_EMIT_SLOTS) s_pix[wave][slot] = xy + (b << 16);
                         slot += set;
                     }
                 }
