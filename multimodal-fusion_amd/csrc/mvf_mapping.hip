@@ -1294,7 +1294,10 @@ __global__ __launch_bounds__(256) void mi_fill_kernel(
 //     contiguous piece of the output.  No sort, no second look at the id map.
 // Pair records are laid out [view][point position].
 constexpr unsigned NE_NO_MASKS = 0xffffffffu;      // as first entry: the pair's entries did not fit the buffer
-constexpr int NE_CHUNK = 16;                       // words per chunk: a row of 16 lanes
+#ifndef MVF_NE_CHUNK
+#define MVF_NE_CHUNK 16
+#endif
+constexpr int NE_CHUNK = MVF_NE_CHUNK;             // words per chunk: that many neighbouring lanes take one
 
 // x: first entry; y: first column | first row group << 16; z, w: low 32 and (in
 // the low half of w) high 16 bits of the pair's first pixel in the output minus
@@ -1537,7 +1540,7 @@ __global__ __launch_bounds__(256) void ne_count_kernel(
         : bits_before[(mo >> 3) + ((ne_items(e.xa, e.xb, e.ya, e.yb) + 7u) >> 3)] - bits_before[mo >> 3];
 }
 
-// pixels <- the pixels of all pairs.  A wave takes 4 chunks (up to NE_CHUNK words
+// pixels <- the pixels of all pairs.  A wave takes 64 / NE_CHUNK chunks (up to NE_CHUNK words
 // of one pair each), a lane one word: it rebuilds the pixels of the word's set
 // bits from the pair's box and lays them out, in LDS, where they stand among the
 // wave's pixels; the pixels of a chunk are neighbours in the output (entry order
@@ -1557,7 +1560,6 @@ __global__ __launch_bounds__(256) void ne_emit_kernel(
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned sub = lane / NE_CHUNK, wl = lane % NE_CHUNK;
     constexpr unsigned PER_WAVE = 64 / NE_CHUNK;
-    static_assert(PER_WAVE == 4, "four chunks per wave");
     const u64 stride = (u64)gridDim.x * 4u * PER_WAVE;
     const uint4 no_chunk = make_uint4(0u, 0u, 0u, 0u);
     u64 c0 = ((u64)blockIdx.x * 4u + wave) * PER_WAVE;
@@ -1595,8 +1597,12 @@ __global__ __launch_bounds__(256) void ne_emit_kernel(
         const unsigned total = __shfl(inc, 63, 64);
         const unsigned slot0 = inc - cnt;
         // the pixels of a chunk are consecutive in the output: first slot and first place of each
-        const unsigned s1 = __shfl(slot0, 16, 64), s2 = __shfl(slot0, 32, 64), s3 = __shfl(slot0, 48, 64);
-        const unsigned a0 = __shfl(at, 0, 64), a1 = __shfl(at, 16, 64), a2 = __shfl(at, 32, 64), a3 = __shfl(at, 48, 64);
+        unsigned c_slot[PER_WAVE], c_at[PER_WAVE];
+#pragma unroll
+        for (unsigned q = 0; q < PER_WAVE; ++q) {
+            c_slot[q] = __shfl(slot0, (int)(q * NE_CHUNK), 64);
+            c_at[q] = __shfl(at, (int)(q * NE_CHUNK), 64);
+        }
         for (unsigned win = 0; win < total; win += NE_EMIT_SLOTS) {
             // entry by entry (a byte of the word: one column, 8 rows), all lanes in step
             unsigned slot = slot0 - win, c_ = col, r_ = rg;
@@ -1618,7 +1624,11 @@ __global__ __launch_bounds__(256) void ne_emit_kernel(
             const unsigned here = total - win < (unsigned)NE_EMIT_SLOTS ? total - win : (unsigned)NE_EMIT_SLOTS;
             for (unsigned t = lane; t < here; t += 64) {
                 const unsigned sl = win + t;
-                const unsigned to = sl >= s3 ? a3 + (sl - s3) : sl >= s2 ? a2 + (sl - s2) : sl >= s1 ? a1 + (sl - s1) : a0 + sl;
+                unsigned base_slot = 0u, base_at = c_at[0];
+#pragma unroll
+                for (unsigned q = 1; q < PER_WAVE; ++q)
+                    if (sl >= c_slot[q]) { base_slot = c_slot[q]; base_at = c_at[q]; }
+                const unsigned to = base_at + (sl - base_slot);
                 if ((i64)to < pix_capacity) pixels[to] = s_pix[wave][t];
             }
             __builtin_amdgcn_wave_barrier();
@@ -2189,8 +2199,8 @@ struct MapWorkspace {
             bits_blocks = ar.take<unsigned>((size_t)cdiv(mask_capacity / 8 + 1, 2048) + 1);
             ne_pairs = ar.take<uint4>((size_t)n * V);
             // a seen pair has at least one chunk and at least one (splat, tile) entry; then one
-            // chunk per NE_CHUNK words (128 entries)
-            chunk_capacity = pair_capacity + mask_capacity / 128 + 1;
+            // chunk per NE_CHUNK words
+            chunk_capacity = pair_capacity + mask_capacity / (8 * NE_CHUNK) + 1;
             ne_chunks = ar.take<uint4>((size_t)chunk_capacity);
         }
         used = ar.off;
