@@ -811,10 +811,11 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     cfg = args.config
+    cpu_leg = not args.no_cpu_baseline and world == 1      # the CPU baseline is timed at N = 1 only
     if cfg == "c3":
-        line = run_qkv(args, rank, world, device, dist, cpu_leg=not args.no_cpu_baseline)
+        line = run_qkv(args, rank, world, device, dist, cpu_leg=cpu_leg)
     else:
-        line = run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=not args.no_cpu_baseline)
+        line = run_map_pool(cfg, args, rank, world, device, dist, cpu_leg=cpu_leg)
 
     if rank == 0 and world == 1 and cfg == "c2" and args.exact and not args.no_extras:
         # short runs of the other workloads, so that one invocation records them all
