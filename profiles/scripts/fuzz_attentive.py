@@ -1,9 +1,10 @@
 """Randomised parity sweep of the attentive pools (QKVBimodalCSRPool, GroupBimodalCSRPool; fused
 fp32 MFMA chains with their epilogues) against the CPU oracle (tolerance of tests/test_gpu_attentive_pools.py; a case that misses it is
-re-run through the composed torch path as a third float32 implementation): random widths, group counts, key
+judged against the float64 evaluation of oracle/mvf_exact64.py): random widths, group counts, key
 sizes, gating / scaling switches, modality features mixed into keys / queries / scores, map
 encoder pools and fusions, random view counts per point (empty points, up to 40 views).
-usage (GPU box, repo root): python profiles/scripts/fuzz_attentive.py [cases] [first seed]"""
+usage (GPU box, repo root): python profiles/scripts/fuzz_attentive.py [cases] [first seed] [stats]
+(stats: every case is also evaluated in float64 and through the composed path; quantiles at the end)"""
 import sys
 import time
 
@@ -18,6 +19,7 @@ from mvfusion import pooling
 from test_gpu_attentive_pools import _close, _np_sd, _random_module
 
 DEV = "cuda:0"
+STATS = None        # "stats" mode: (fused, oracle, composed) distance from float64 of every case
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
@@ -70,25 +72,42 @@ def one_case(seed):
         desc = f"group use_mod={use_mod}"
     tag = (f"seed {seed} {desc} n={n} Vw={Vw} maxviews={int(counts.max())} mod={in_mod}->{out_mod} "
            f"map={in_map} {pool} {fusion} {kw}")
+    def distances():
+        """Relative distance from the float64 value of the case, on its large elements, of the
+        fused kernels, of the oracle (a float32 evaluation too: normally distributed features
+        make some outputs cancelling sums) and of the composed torch path (Linear / BatchNorm on
+        rocBLAS + the CSR kernels, a third float32 implementation)."""
+        import mvf_exact64 as x64
+        from mvfusion import training
+        is_qkv = isinstance(mod, pooling.QKVBimodalCSRPool)
+        fn = training.qkv_pool if is_qkv else training.group_pool
+        with torch.no_grad():
+            third = mod._forward_train(fn, T(x_main) if is_qkv else None,
+                                       T(x_mod), T(x_map), T(ptr)).cpu().numpy()
+        sd = _np_sd(mod)
+        if is_qkv:
+            exact = x64.qkv_pool(x_main, x_mod, x_map, ptr, sd, pool=tuple(pool.split("_")), fusion=fusion,
+                                 **kw, **q)
+        else:
+            exact = x64.group_pool(x_mod, x_map, ptr, sd, pool=tuple(pool.split("_")), fusion=fusion,
+                                   use_mod=use_mod, **kw)
+        big = np.abs(exact) > 0.1 * np.abs(exact).max()
+        # (a closed gate gives an output of zeros: no large elements, distance 0)
+        far = lambda a: float((np.abs(a - exact)[big] / np.abs(exact[big])).max()) if big.any() else 0.0
+        return far(got.cpu().numpy()), far(want), far(third)
+
+    if STATS is not None:
+        STATS.append(distances())
     try:
         rel, ab = _close(got, want)
     except AssertionError as e:
-        # which side is off?  A third float32 implementation: the composed path
-        # (torch Linear / BatchNorm on rocBLAS + the CSR kernels)
-        from mvfusion import training
-        fn = training.qkv_pool if isinstance(mod, pooling.QKVBimodalCSRPool) else training.group_pool
-        with torch.no_grad():
-            third = mod._forward_train(fn, T(x_main) if isinstance(mod, pooling.QKVBimodalCSRPool) else None,
-                                       T(x_mod), T(x_map), T(ptr)).cpu().numpy()
-        g = got.cpu().numpy()
-        scale = float(np.abs(want).max())
-        d = lambda a, b: float(np.abs(a - b).max()) / scale
-        note = (f"fused-oracle {d(g, want):.1e} composed-oracle {d(third, want):.1e} "
-                f"fused-composed {d(g, third):.1e} of the largest magnitude")
-        # normally distributed features make some outputs cancelling sums: when torch's own
-        # float32 path is as far from the oracle as the fused kernels are, the case measures the
-        # conditioning of the problem, not the kernels
-        if d(g, want) <= 2.0 * d(third, want):
+        f_fused, f_oracle, f_third = distances()
+        note = (f"relative distance from the float64 value on the large elements: fused {f_fused:.1e} "
+                f"oracle {f_oracle:.1e} composed {f_third:.1e}")
+        # Badly conditioned: the oracle is itself farther than a third of the tolerance from the
+        # float64 value (the rule of the fixture tests), and the fused kernels are no farther
+        # from it than twice the worse of the two other float32 evaluations.
+        if f_oracle > 1e-5 / 3.0 and f_fused <= 2.0 * max(f_oracle, f_third):
             return f"{tag} ILL-CONDITIONED {note}"
         raise AssertionError(tag + " :: " + note + " :: " + str(e))
     return f"{tag} rel {rel:.1e} abs {ab:.1e}"
@@ -97,6 +116,8 @@ def one_case(seed):
 if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    if len(sys.argv) > 3 and sys.argv[3] == "stats":
+        STATS = []
     bad, t0 = 0, time.time()
     for seed in range(first, first + cases):
         try:
@@ -104,5 +125,15 @@ if __name__ == "__main__":
         except Exception as e:          # report and go on: the sweep lists every failing seed
             bad += 1
             print("FAIL", seed, type(e).__name__, str(e)[:400].replace("\n", " "), flush=True)
+    if STATS:
+        a = np.array(STATS)
+        a = a[(a > 0).all(axis=1)]
+        q = lambda v: " / ".join(f"{x:.1e}" for x in np.quantile(v, [0.5, 0.9, 0.99, 1.0]))
+        print("distance from the float64 value (median / 90% / 99% / max over the cases):")
+        for name, col in zip(("fused", "oracle", "composed"), a.T):
+            print(f"  {name:9s} {q(col)}")
+        print(f"  fused / oracle   ratio, median {np.median(a[:, 0] / a[:, 1]):.2f}; "
+              f"composed / oracle {np.median(a[:, 2] / a[:, 1]):.2f}; "
+              f"fused / composed {np.median(a[:, 0] / a[:, 2]):.2f}")
     print(f"{cases} cases, {bad} failures, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
