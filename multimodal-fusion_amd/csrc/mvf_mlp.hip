@@ -18,7 +18,8 @@
 // k-half 1: second half).  The instruction is an exact fp32 fmaf chain; only
 // the summation order differs from a sequential dot product.
 // BatchNorm (eval) and the bias collapse into one scale and one shift per
-// output channel, applied with the activation on the accumulators.
+// output channel: the scale is multiplied into the weights, the shift is added to
+// the finished sums (mlp_late4), the activation follows on the accumulators.
 //
 // Limits of one launch: every layer's output width <= 64 and every layer
 // after the first has input width <= 64; the first layer's input is streamed
@@ -203,8 +204,8 @@ __device__ __forceinline__ void mlp_epilogue(
 }
 
 // Activation of four neighbouring accumulators (registers 4 g .. 4 g + 3), in
-// place.  Scale and shift are already in: the weights in LDS carry the channel
-// scale and the accumulators start from the channel shift.
+// place.  The scale is already in (the weights in LDS carry the channel scale); the shift
+// has been added by mlp_late4 or was the accumulators' start (mlp_init_acc).
 __device__ __forceinline__ void mlp_epilogue4(floatx16 &acc, int g, const mvf_mlp_layer &L)
 {
     // leaky(v) = max(v, slope * v) for every slope <= 1 (the host rejects larger ones);
@@ -213,6 +214,21 @@ __device__ __forceinline__ void mlp_epilogue4(floatx16 &acc, int g, const mvf_ml
     const float s = L.act ? L.slope : 1.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[4 * g + e] = fmaxf(acc[4 * g + e], __fmul_rn(acc[4 * g + e], s));
+}
+
+// The channel shifts of a layer join its finished sums, four registers of block nb at a time
+// (float32 chain and the narrow three-layer split-bf16 chain; the accumulators start from
+// zero).  Started from the shift instead, a sum of few terms rounds every partial sum at the
+// shift's magnitude: with 2 to 8 (live) input columns that was 1.3 to 1.8 times as far from the
+// float64 value as the reference's order (sum, then scale and shift), and the pools' scores,
+// gates and softmax behind it magnify the difference.  From 32 input columns on the two orders
+// measure the same, which is why the wide two-layer split-bf16 chain (64 columns per layer,
+// vector issue to spare for nothing) keeps the start from the shift (mlp_init_acc).
+__device__ __forceinline__ void mlp_late4(floatx16 &acc, int nb, int g, const float *sh, int kh)
+{
+    const float4 v = *(const float4 *)(sh + nb * 32 + 4 * kh + 8 * g);
+    acc[4 * g] = __fadd_rn(acc[4 * g], v.x); acc[4 * g + 1] = __fadd_rn(acc[4 * g + 1], v.y);
+    acc[4 * g + 2] = __fadd_rn(acc[4 * g + 2], v.z); acc[4 * g + 3] = __fadd_rn(acc[4 * g + 3], v.w);
 }
 
 // Accumulators of block nb start from the channel shifts of the layer.
@@ -248,10 +264,12 @@ __device__ __forceinline__ void mlp_store4(
 // between matrix instructions.  PASS 0: n0 and n1 together; 1: n0 only (acc is
 // finished in place); 2: n1 only from the finished acc, and after every group
 // the caller's `between(g)` runs (epilogue + store of a finished n0 group).
+// late: the previous layer's shifts, added to its sums here (mlp_late4).
 template <int PASS, class F>
 __device__ __forceinline__ void mlp_next_block(
     floatx16 &acc, int nb_in, const float *wp, int cop2, bool wide_out,
-    const mvf_mlp_layer &Lprev, floatx16 &n0, floatx16 &n1, F between, int dbg = 0)
+    const mvf_mlp_layer &Lprev, floatx16 &n0, floatx16 &n1, F between, int dbg,
+    const float *late, int kh)
 {
     const float *w = wp + nb_in * 32 * cop2;
 #pragma unroll
@@ -262,6 +280,7 @@ __device__ __forceinline__ void mlp_next_block(
             if (PASS != 2) w0[e] = (dbg & 4) ? 0.5f : w[(8 * g + e) * cop2];
             if (PASS == 2 || (PASS == 0 && wide_out)) w1[e] = (dbg & 4) ? 0.5f : w[(8 * g + e) * cop2 + 32];
         }
+        if (PASS != 2) mlp_late4(acc, nb_in, g, late, kh);
         if (PASS != 2 && !(dbg & 8)) mlp_epilogue4(acc, g, Lprev);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -754,8 +773,8 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
         const i64 row = base + wave * 32 + jrow;
         const bool live = row < A.rows;
         floatx16 acc0, acc1;
-        mlp_init_acc(acc0, 0, sh, kh);
-        mlp_init_acc(acc1, 1, sh, kh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;     // the shifts come at the end (mlp_late4)
         // dot epilogue: the row's query index now, its query values after the first
         // layer, so that neither load is waited for at the end of the tile
         const int qseg = (A.dot_out && live) ? A.dot_seg[row] : 0;
@@ -891,27 +910,30 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             const int cop2 = cop_of(l + 1);
             // the lane's register r of block nb is input channel nb * 32 + acc_channel(r, kh)
             const float *wp = smem + (l == 0 ? woff[1] : woff[2]) + (4 * kh) * cop2 + jrow;
+            const float *late = sh + l * MLP_MAX_C;     // layer l takes its shifts here
             floatx16 n0, n1;
-            mlp_init_acc(n0, 0, sh + (l + 1) * MLP_MAX_C, kh);
-            mlp_init_acc(n1, 1, sh + (l + 1) * MLP_MAX_C, kh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) n0[r] = n1[r] = 0.f;
             if (l + 2 == nlayers && wide_out) {
                 // last layer with two output blocks: n0 first, then n1 while the
                 // finished n0 is scaled and stored group by group
                 const mvf_mlp_layer &L2 = A.L[l + 1];
-                mlp_next_block<1>(acc0, 0, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A));
-                if (wide_in) mlp_next_block<1>(acc1, 1, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A));
+                mlp_next_block<1>(acc0, 0, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A), late, kh);
+                if (wide_in) mlp_next_block<1>(acc1, 1, wp, cop2, true, L, n0, n1, nothing, MLP_DBG(A), late, kh);
                 const int per = wide_in ? 2 : 1;      // n1 groups per n0 group
                 auto drain = [&](int step) {
                     if ((step + 1) % per == 0) {
                         const int g = step / per;
+                        mlp_late4(n0, 0, g, sh + (l + 1) * MLP_MAX_C, kh);
                         mlp_epilogue4(n0, g, L2);
                         if ((POOL == 0 || POOL == 3) && live) mlp_store4(n0, 0, g, A, vec_out, L2.cout, row, kh);
                     }
                 };
-                mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A));
-                if (wide_in) mlp_next_block<2>(acc1, 1, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A));
+                mlp_next_block<2>(acc0, 0, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A), late, kh);
+                if (wide_in) mlp_next_block<2>(acc1, 1, wp, cop2, true, L, n0, n1, drain, MLP_DBG(A), late, kh);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    mlp_late4(n1, 1, g, sh + (l + 1) * MLP_MAX_C, kh);
                     mlp_epilogue4(n1, g, L2);
                     if ((POOL == 0 || POOL == 3) && live) mlp_store4(n1, 1, g, A, vec_out, L2.cout, row, kh);
                 }
@@ -919,8 +941,8 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
                 if (POOL) goto pool_tail;
                 goto tile_done;
             }
-            mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A));
-            if (wide_in) mlp_next_block<0>(acc1, 1, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A));
+            mlp_next_block<0>(acc0, 0, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A), late, kh);
+            if (wide_in) mlp_next_block<0>(acc1, 1, wp, cop2, wide_out, L, n0, n1, nothing, MLP_DBG(A), late, kh);
             acc0 = n0;
             acc1 = n1;
         }
@@ -934,6 +956,7 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             float part = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                mlp_late4(acc0, 0, g, sh + (nlayers - 1) * MLP_MAX_C, kh);
                 mlp_epilogue4(acc0, g, L);
                 const int c = 4 * kh + 8 * g;
 #pragma unroll
@@ -948,12 +971,14 @@ __device__ __forceinline__ void mlp_chain_body(const MlpArgs &A)
             const bool wide = cop_of(nlayers - 1) > 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                mlp_late4(acc0, 0, g, sh + (nlayers - 1) * MLP_MAX_C, kh);
                 mlp_epilogue4(acc0, g, L);
                 if ((POOL == 0 || POOL == 3) && live) mlp_store4(acc0, 0, g, A, vec_out, L.cout, row, kh);
             }
             if (wide) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
+                    mlp_late4(acc1, 1, g, sh + (nlayers - 1) * MLP_MAX_C, kh);
                     mlp_epilogue4(acc1, g, L);
                     if ((POOL == 0 || POOL == 3) && live) mlp_store4(acc1, 1, g, A, vec_out, L.cout, row, kh);
                 }
@@ -1512,9 +1537,10 @@ void mlp_narrow3_bf3_kernel(MlpArgs A)
         for (int q = 0; q < NQ0; ++q) load_piece(xn, base + stride, ga1, gb1, q);
         gather_of(base + 2 * stride, ga1, gb1);
         floatx16 acc, nacc, macc;
-        mlp_init_acc(acc, 0, sh, kh);
-        mlp_init_acc(nacc, 0, sh + MLP_MAX_C, kh);
-        mlp_init_acc(macc, 0, sh + 2 * MLP_MAX_C, kh);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;      // the shifts come at the end (mlp_late4)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nacc[r] = macc[r] = 0.f;
         // ---- first layer ----
 #pragma unroll
         for (int q = 0; q < NQ0; ++q) {
@@ -1538,6 +1564,8 @@ void mlp_narrow3_bf3_kernel(MlpArgs A)
             }
         }
         // ---- second layer: k-step 0 = registers 0 .. 7 of the first layer's block ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mlp_late4(acc, 0, g, sh, kh);
         float v8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = acc[j];
@@ -1550,6 +1578,8 @@ void mlp_narrow3_bf3_kernel(MlpArgs A)
         cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
         bf3_kstep1(aw, w0 + ((NQ0 + 2) * 3) * 64, cur, nacc, [&](int) {});
         // ---- third layer ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mlp_late4(nacc, 0, g, sh + MLP_MAX_C, kh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = nacc[j];
         sp.all(v8, true, slope1);
@@ -1566,6 +1596,8 @@ void mlp_narrow3_bf3_kernel(MlpArgs A)
         cur[0] = sp.p1; cur[1] = sp.p2; cur[2] = sp.p3;
         asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]));
         // ---- activation of the last layer, then the dot product or the rows ----
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mlp_late4(macc, 0, g, sh + 2 * MLP_MAX_C, kh);
 #pragma unroll
         for (int r = 0; r < 16; ++r) macc[r] = max_raw(macc[r], __fmul_rn(macc[r], slope2));
         if (A.dot_out) {

@@ -124,7 +124,7 @@ if __name__ == "__main__":
             print("ok |", one_case(seed), flush=True)
         except Exception as e:          # report and go on: the sweep lists every failing seed
             bad += 1
-            print("FAIL", seed, type(e).__name__, str(e)[:400].replace("\n", " "), flush=True)
+            print("FAIL", seed, type(e).__name__, str(e)[:900].replace("\n", " "), flush=True)
     if STATS:
         a = np.array(STATS)
         a = a[(a > 0).all(axis=1)]
