@@ -1238,6 +1238,90 @@ class CenterRoll(ImageTransform):
         return data, images
 
 
+def _loaded(images, who):
+    """The reference's image-side transforms read the files on demand
+    (``images.load()``); file IO is not part of this package: the feature maps
+    must be there."""
+    if images.x is None:
+        raise ValueError(f"{who}: the images hold no feature maps (x is None); load them first")
+    return images.x
+
+
+class AddPixelHeightFeature(ImageTransform):
+    """Appends the pixel's height in [0, 1] to the image features
+    (core/data_transform/multimodal/image.py:1163-1176)."""
+
+    def _process(self, data, images):
+        x = _loaded(images, "AddPixelHeightFeature")
+        batch, _, height, width = x.shape
+        feat = torch.linspace(0, 1, height, device=x.device).float()
+        images.x = torch.cat((x, feat.view(1, 1, height, 1).repeat(batch, 1, 1, width)), 1)
+        return data, images
+
+
+class AddPixelWidthFeature(ImageTransform):
+    """Appends the pixel's width in [0, 1] to the image features
+    (core/data_transform/multimodal/image.py:1179-1192)."""
+
+    def _process(self, data, images):
+        x = _loaded(images, "AddPixelWidthFeature")
+        batch, _, height, width = x.shape
+        feat = torch.linspace(0, 1, width, device=x.device).float()
+        images.x = torch.cat((x, feat.view(1, 1, 1, width).repeat(batch, 1, height, 1)), 1)
+        return data, images
+
+
+class RandomHorizontalFlip(ImageTransform):
+    """With probability ``p`` (one ``torch.rand(1)`` draw per setting, as the
+    reference) flips the feature maps along the width and mirrors the pixel
+    columns of the mappings (core/data_transform/multimodal/image.py:1195-1218)."""
+
+    def __init__(self, p=0.50):
+        self.p = p
+
+    def _process(self, data, images):
+        x = _loaded(images, "RandomHorizontalFlip")
+        if torch.rand(1) <= self.p:
+            images.x = torch.flip(x, [3])
+            width = x.shape[3]
+            images.mappings.pixels[:, 0] = width - 1 - images.mappings.pixels[:, 0]
+        return data, images
+
+
+class ToFloatImage(ImageTransform):
+    """[0, 255] uint8 feature maps to [0, 1] float32
+    (core/data_transform/multimodal/image.py:1221-1232)."""
+
+    def _process(self, data, images):
+        images.x = _loaded(images, "ToFloatImage").float() / 255
+        return data, images
+
+
+class Normalize(ImageTransform):
+    """Per-channel ``(x - mean) / std`` of float feature maps
+    (core/data_transform/multimodal/image.py:1271-1284, a wrapper of
+    ``torchvision.transforms.Normalize``, which is restated here: torchvision is
+    not a dependency of this package)."""
+
+    def __init__(self, mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]):
+        self.mean = mean
+        self.std = std
+
+    def _process(self, data, images):
+        x = _loaded(images, "Normalize")
+        if not x.is_floating_point():
+            raise TypeError(f"Input tensor should be a float tensor. Got {x.dtype}.")
+        mean = torch.as_tensor(self.mean, dtype=x.dtype, device=x.device)
+        std = torch.as_tensor(self.std, dtype=x.dtype, device=x.device)
+        if (std == 0).any():
+            raise ValueError(f"std evaluated to zero after conversion to {x.dtype}, leading to division by zero.")
+        images.x = (x - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+        return data, images
+
+    def __repr__(self):
+        return f"Normalize(mean={self.mean}, std={self.std})"
+
+
 class PickMappingsFromMappingFeatures(ImageTransform):
     """Drops the views whose mapping features fall outside per-feature lower /
     upper bounds, both exclusive (core/data_transform/multimodal/image.py:877-931)."""

@@ -946,6 +946,49 @@ def gen_roll_and_credit():
     save("roll_and_credit", **arrs)
 
 
+def gen_image_side():
+    """The image-side transforms between MapImages and the model that touch the
+    feature maps or the mappings: ToFloatImage, AddPixelHeightFeature,
+    AddPixelWidthFeature, RandomHorizontalFlip
+    (core/data_transform/multimodal/image.py:1163-1232) on small uint8 images."""
+    image, tr = ref["image"], ref["transforms"]
+    rng = np.random.default_rng(202)
+    n, n_img, W, H = 300, 4, 40, 24
+    pid = np.sort(rng.integers(0, n, 500)).astype(np.int64)
+    iid = rng.integers(0, n_img, 500).astype(np.int64)
+    pix = np.stack([rng.integers(0, W, 500), rng.integers(0, H, 500)], 1).astype(np.int16)
+    keys = np.unique(np.stack([pid, iid, pix[:, 0], pix[:, 1]], 1), axis=0)
+    pid, iid, pix = keys[:, 0], keys[:, 1], keys[:, 2:].astype(np.int16)
+    feat = rng.random((pid.shape[0], 2)).astype(np.float32)
+    x = rng.integers(0, 256, (n_img, 3, H, W)).astype(np.uint8)
+
+    def fresh():
+        m = image.ImageMapping.from_dense(T(pid), T(iid), T(pix.copy()), T(feat), num_points=n)
+        return image.SameSettingImageData(
+            path=np.array([f"v{i}" for i in range(n_img)], dtype='O'), pos=T(rng.random((n_img, 3))),
+            ref_size=(W, H), proj_upscale=1, downscale=1, mappings=m, x=T(x.copy()))
+
+    data = _refshim.Data(pos=T(rng.random((n, 3)).astype(np.float32)))
+    arrs = dict(x=x, size=np.array([W, H]), n=n)
+    arrs.update(mapping_arrays(fresh().mappings, "in_"))
+    _, out = tr.ToFloatImage()(data, fresh())
+    arrs["float_x"] = out.x.numpy()
+    _, out = tr.AddPixelHeightFeature()(data, tr.ToFloatImage()(data, fresh())[1])
+    arrs["height_x"] = out.x.numpy()
+    _, out = tr.AddPixelWidthFeature()(data, tr.ToFloatImage()(data, fresh())[1])
+    arrs["width_x"] = out.x.numpy()
+    # the flip: always, never, and with the probability decided by torch's seeded draw
+    for tag, p, seed in (("flip1", 1.0, 0), ("flip0", 0.0, 0), ("flip_s3", 0.5, 3), ("flip_s4", 0.5, 4),
+                         ("flip_s5", 0.5, 5), ("flip_s6", 0.5, 6)):
+        torch.manual_seed(seed)
+        _, out = tr.RandomHorizontalFlip(p=p)(data, fresh())
+        arrs[tag + "_seed"] = seed
+        arrs[tag + "_p"] = p
+        arrs[tag + "_x"] = out.x.numpy()
+        arrs.update(mapping_arrays(out.mappings, tag + "_"))
+    save("image_side", **arrs)
+
+
 def gen_attention_variants():
     """Option combinations of the attentive pools beyond the defaults: modality
     features mixed into keys / queries / scores, the other map encoders, the
@@ -999,6 +1042,6 @@ def gen_attention_variants():
 if __name__ == "__main__":
     which = sys.argv[1:] or [
         "projection", "visibility", "wide_cameras", "model", "depth_map", "map_images", "lexops",
-        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping", "crop_groups", "roll_and_credit"]
+        "from_dense", "mapped_features", "image_batch", "select_points", "pooling", "attention_pools", "attention_variants", "training", "neighborhood_features", "image_selection", "cropping", "crop_groups", "roll_and_credit", "image_side"]
     for w in which:
         globals()["gen_" + w]()

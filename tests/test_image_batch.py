@@ -279,3 +279,47 @@ def test_pick_images_from_memory_credit(golden):
         PickImagesFromMemoryCredit()
     with pytest.raises(AssertionError):
         PickImagesFromMemoryCredit(credit=10)(data, ImageData([_roll_sample(g, False)]))
+
+
+def _side_sample(g):
+    W, H = (int(v) for v in g["size"])
+    m = mapping(g, "in_")
+    m.pixels = m.pixels.clone()            # (the flip edits the pixels in place)
+    n_img = g["x"].shape[0]
+    return SameSettingImageData(
+        path=[f"v{i}" for i in range(n_img)], pos=torch.zeros(n_img, 3, device=DEV), ref_size=(W, H),
+        proj_upscale=1, downscale=1, mappings=m, x=T(g["x"]))
+
+
+def test_image_side_transforms(golden):
+    """ToFloatImage, AddPixelHeightFeature, AddPixelWidthFeature and RandomHorizontalFlip (the
+    flip with torch's seeded draw) against the reference's own run; Normalize against the formula
+    of torchvision's transform, which the reference wraps (torchvision is not installed here: no
+    fixture, the formula is the pin)."""
+    from mvfusion import transforms as tr
+    g = golden("image_side")
+    data = _Data(pos=torch.zeros(int(g["n"]), 3, device=DEV))
+    _, f = tr.ToFloatImage()(data, _side_sample(g))
+    assert f.x.dtype == torch.float32 and np.array_equal(N(f.x), g["float_x"])
+    _, out = tr.AddPixelHeightFeature()(data, tr.ToFloatImage()(data, _side_sample(g))[1])
+    assert np.array_equal(N(out.x), g["height_x"])
+    _, out = tr.AddPixelWidthFeature()(data, tr.ToFloatImage()(data, _side_sample(g))[1])
+    assert np.array_equal(N(out.x), g["width_x"])
+    flipped = 0
+    for tag in ("flip1", "flip0", "flip_s3", "flip_s4", "flip_s5", "flip_s6"):
+        torch.manual_seed(int(g[tag + "_seed"]))
+        _, out = tr.RandomHorizontalFlip(p=float(g[tag + "_p"]))(data, _side_sample(g))
+        assert np.array_equal(N(out.x), g[tag + "_x"]), tag
+        same(out.mappings, g, tag + "_")
+        flipped += int(not np.array_equal(g[tag + "_x"], g["x"]))
+    assert 1 < flipped < 6                 # both outcomes of the seeded draw are in the fixture
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    _, out = tr.Normalize(mean, std)(data, f)
+    want = (g["float_x"] - np.asarray(mean, np.float32).reshape(1, 3, 1, 1)) / np.asarray(std, np.float32).reshape(1, 3, 1, 1)
+    assert np.array_equal(N(out.x), want.astype(np.float32))
+    with pytest.raises(TypeError):
+        tr.Normalize()(data, _side_sample(g))                  # uint8 maps
+    empty = _side_sample(g)
+    empty.x = None
+    with pytest.raises(ValueError):
+        tr.ToFloatImage()(data, empty)
