@@ -1254,7 +1254,7 @@ class AddPixelHeightFeature(ImageTransform):
     def _process(self, data, images):
         x = _loaded(images, "AddPixelHeightFeature")
         batch, _, height, width = x.shape
-        feat = torch.linspace(0, 1, height, device=x.device).float()
+        feat = torch.linspace(0, 1, height).float().to(x.device)      # (the host's values, as the reference)
         images.x = torch.cat((x, feat.view(1, 1, height, 1).repeat(batch, 1, 1, width)), 1)
         return data, images
 
@@ -1266,7 +1266,7 @@ class AddPixelWidthFeature(ImageTransform):
     def _process(self, data, images):
         x = _loaded(images, "AddPixelWidthFeature")
         batch, _, height, width = x.shape
-        feat = torch.linspace(0, 1, width, device=x.device).float()
+        feat = torch.linspace(0, 1, width).float().to(x.device)       # (the host's values, as the reference)
         images.x = torch.cat((x, feat.view(1, 1, 1, width).repeat(batch, 1, height, 1)), 1)
         return data, images
 
@@ -1293,7 +1293,10 @@ class ToFloatImage(ImageTransform):
     (core/data_transform/multimodal/image.py:1221-1232)."""
 
     def _process(self, data, images):
-        images.x = _loaded(images, "ToFloatImage").float() / 255
+        x = _loaded(images, "ToFloatImage")
+        # a tensor divisor: the device's division by a Python scalar multiplies by the rounded
+        # reciprocal, which is one unit in the last place off the reference's quotient for some values
+        images.x = x.float() / torch.full((1,), 255., device=x.device)
         return data, images
 
 
