@@ -105,61 +105,118 @@ __global__ __launch_bounds__(256) void segment_csr_kernel(
 // its chain of loads.  Here a wave takes a segment: lane = (row group, channel)
 // with 64 >> cp_log row groups of 1 << cp_log >= min(C, 64) channels,
 // SEG_LONG_LOADS steps of rows in flight, and a final combine across the row
-// groups.  Ties (+0.0 /
-// -0.0 compare equal) go to the first row, as in the in-order fold, and a NaN
-// counts where that fold counts it (it sticks when it is the segment's first
-// row and is passed over anywhere else: every comparison with it is false), so
-// the result is bit-identical to segment_csr_kernel's.
+// groups.  The result is bit-identical to segment_csr_kernel's in-order fold
+// (acc = first row; x > acc replaces): ties (+0.0 / -0.0 compare equal) go to the
+// first row, a NaN sticks when it is the segment's first row and is passed over
+// anywhere else.
+//
+// The kernel is bound by vector issue (a million waves of a few dozen rows each),
+// so the common case is kept to five instructions per load step: v_max_f32 /
+// v_min_f32 on values preset to -inf / +inf, which gives the fold's result
+// whenever no row holds a NaN and the result is not a zero (the only cases in
+// which the order of the rows shows).  A wave that saw a NaN, or whose result is
+// +-0 in some channel, repeats the segment with the exact procedure
+// (seg_long_exact: row index of every candidate kept, first row wins).
 #ifndef MVF_SEG_LONG_LOADS
 #define MVF_SEG_LONG_LOADS 16
 #endif
 constexpr int SEG_LONG_LOADS = MVF_SEG_LONG_LOADS;       // rows a lane has in flight
 
 template <int MODE>
+__device__ __forceinline__ float seg_long_exact(
+    const float *q, unsigned n, bool live, int ro, int rp, int cp, int C)
+{
+    auto better = [](float x, float y) { return MODE == MVF_REDUCE_MAX ? x > y : x < y; };
+    float acc = 0.f;
+    unsigned at = 0xffffffffu;                        // row (relative to the segment) the value comes from
+    for (unsigned r = (unsigned)ro; r < n && live; r += (unsigned)(SEG_LONG_LOADS * rp)) {
+        float x[SEG_LONG_LOADS];
+        bool ok[SEG_LONG_LOADS];
+#pragma unroll
+        for (int k = 0; k < SEG_LONG_LOADS; ++k) {
+            ok[k] = r + (unsigned)(k * rp) < n;
+            x[k] = ok[k] ? q[(size_t)(r + (unsigned)(k * rp)) * C] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < SEG_LONG_LOADS; ++k) {
+            const unsigned rk = r + (unsigned)(k * rp);
+            // a lane starts from its first number (or from row 0, whatever it holds)
+            const bool start = at == 0xffffffffu && (x[k] == x[k] || rk == 0u);
+            if (ok[k] && (start || better(x[k], acc))) { acc = x[k]; at = rk; }
+        }
+    }
+    // combine the row groups (lane bits cp_log .. 5)
+    for (int d = 32; d >= cp; d >>= 1) {
+        const float ov = __shfl_xor(acc, d, 64);
+        const unsigned oat = __shfl_xor(at, d, 64);
+        // (only row 0 can have left a NaN: it wins over everything)
+        const bool take = oat != 0xffffffffu && acc == acc &&
+            (at == 0xffffffffu || ov != ov || better(ov, acc) || (!better(acc, ov) && oat < at));
+        if (take) { acc = ov; at = oat; }
+    }
+    return at == 0xffffffffu ? 0.f : acc;
+}
+
+// v_max_f32 / v_min_f32 as written (the builtins add an instruction per operand to quiet
+// signalling NaNs; a wave that meets any NaN takes the exact procedure anyway)
+template <int MODE> __device__ __forceinline__ float seg_fold_raw(float a, float x)
+{
+    float r;
+    if (MODE == MVF_REDUCE_MAX) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(x));
+    else asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(x));
+    return r;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void segment_long_kernel(
     const float *__restrict__ src, int C, int cp_log, const i64 *__restrict__ ptr, i64 nseg,
     float *__restrict__ out)
 {
-    const i64 seg = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave's segment as a scalar: its bounds come through scalar loads
+    const i64 seg = (i64)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (seg >= nseg) return;
     const int lane = threadIdx.x & 63;
     const int cp = 1 << cp_log, rp = 64 >> cp_log;
     const int c = lane & (cp - 1), ro = lane >> cp_log;
     const i64 a = ptr[seg], b = ptr[seg + 1];
-    auto better = [](float x, float y) { return MODE == MVF_REDUCE_MAX ? x > y : x < y; };
+    const unsigned n = (unsigned)(b - a);
+    const float worst = MODE == MVF_REDUCE_MAX ? -INFINITY : INFINITY;
+    // Addresses inside the segment are 32-bit byte offsets from its first row, a scalar base:
+    // two vector instructions per load (add, clamp) and the load takes the base from scalar
+    // registers.  A segment of 2^32 bytes or more takes the exact procedure right away.
+    const char *base = (const char *)(src + (size_t)a * C);
+    const bool huge = ((unsigned long long)n * (unsigned)C) >> 30;
+    const unsigned step = (unsigned)(rp * C) * 4u;    // bytes between two load steps of a lane
     for (int c0 = 0; c0 < C; c0 += cp) {
         const int ch = c0 + c;
         const bool live = ch < C;
-        float acc = 0.f;
-        unsigned at = 0xffffffffu;                    // row (relative to a) the value comes from
         const float *q = src + (size_t)a * C + ch;
-        const unsigned n = (unsigned)(b - a);
-        for (unsigned r = (unsigned)ro; r < n && live; r += (unsigned)(SEG_LONG_LOADS * rp)) {
+        float acc = worst;
+        float chk = 0.f;                              // turns NaN when a row holds a NaN (or an infinity)
+        // Steps past the end read the segment's last row again (same channel), which changes
+        // neither a maximum nor a minimum: no lane mask inside the batch.
+        const unsigned last = ((n - 1u) * (unsigned)C + (unsigned)ch) * 4u;
+        unsigned off = ((unsigned)ro * (unsigned)C + (unsigned)ch) * 4u;
+        for (unsigned r = (unsigned)ro; r < n && live && !huge; r += (unsigned)(SEG_LONG_LOADS * rp)) {
             float x[SEG_LONG_LOADS];
-            bool ok[SEG_LONG_LOADS];
 #pragma unroll
             for (int k = 0; k < SEG_LONG_LOADS; ++k) {
-                ok[k] = r + (unsigned)(k * rp) < n;
-                x[k] = ok[k] ? q[(size_t)(r + (unsigned)(k * rp)) * C] : 0.f;
+                const unsigned o = off + (unsigned)k * step;
+                x[k] = *(const float *)(base + (o < last ? o : last));
             }
 #pragma unroll
             for (int k = 0; k < SEG_LONG_LOADS; ++k) {
-                const unsigned rk = r + (unsigned)(k * rp);
-                // a lane starts from its first number (or from row 0, whatever it holds)
-                const bool start = at == 0xffffffffu && (x[k] == x[k] || rk == 0u);
-                if (ok[k] && (start || better(x[k], acc))) { acc = x[k]; at = rk; }
+                chk = __fmaf_rn(x[k], 0.f, chk);
+                acc = seg_fold_raw<MODE>(acc, x[k]);
             }
+            off += (unsigned)SEG_LONG_LOADS * step;
         }
-        // combine the row groups (lane bits cp_log .. 5)
-        for (int d = 32; d >= cp; d >>= 1) {
-            const float ov = __shfl_xor(acc, d, 64);
-            const unsigned oat = __shfl_xor(at, d, 64);
-            // (only row 0 can have left a NaN: it wins over everything)
-            const bool take = oat != 0xffffffffu && acc == acc &&
-                (at == 0xffffffffu || ov != ov || better(ov, acc) || (!better(acc, ov) && oat < at));
-            if (take) { acc = ov; at = oat; }
-        }
-        if (ro == 0 && live) out[(size_t)seg * C + ch] = at == 0xffffffffu ? 0.f : acc;
+        for (int d = 32; d >= cp; d >>= 1) acc = seg_fold_raw<MODE>(acc, __shfl_xor(acc, d, 64));
+        // the order of the rows shows in the result: a NaN somewhere, or a zero that wins
+        // (+0.0 and -0.0 tie and the first row keeps its sign)
+        if (huge || __ballot(live && (chk != chk || acc == 0.f)) != 0)
+            acc = seg_long_exact<MODE>(q, n, live, ro, rp, cp, C);
+        if (ro == 0 && live) out[(size_t)seg * C + ch] = n == 0 ? 0.f : acc;
     }
 }
 
