@@ -144,6 +144,45 @@ def test_segment_csr_long_segments(mode):
 
 
 @pytest.mark.parametrize("mode", ["max", "min"])
+def test_segment_csr_long_segments_special_values(mode):
+    """The wave-per-segment kernel folds with the hardware's max / min and repeats a segment
+    with the exact first-row-wins procedure when a row holds a NaN, an infinity, or a zero wins:
+    segments of infinities only, mixed infinities and numbers, zeros of both signs that win
+    (all other values on the losing side), a mostly quiet cloud with a few such segments, and
+    segment lengths around the batch of rows a wave has in flight -- bit for bit the in-order
+    fold."""
+    from mvfusion.pooling import segment_csr
+    rng = np.random.default_rng(31)
+    sizes = np.concatenate([rng.integers(17, 200, 600), [63, 64, 65, 127, 128, 129, 256, 1000]])
+    nseg = sizes.shape[0]
+    ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    seg_of = np.repeat(np.arange(nseg), sizes)
+    lose = -1.0 if mode == "max" else 1.0
+    for C_ in (1, 13, 32, 64):
+        x = rng.normal(size=(int(ptr[-1]), C_)).astype(np.float32)
+        kind = rng.integers(0, 8, nseg)                      # per segment; 4..7: left alone
+        rows = lambda k: np.isin(seg_of, np.where(kind == k)[0])
+        x[rows(0)] = np.where(rng.random((int(rows(0).sum()), C_)) < 0.5, np.inf, -np.inf)
+        x[rows(1) & (rng.random(x.shape[0]) < 0.1)] = -np.inf if mode == "max" else np.inf
+        x[rows(2) & (rng.random(x.shape[0]) < 0.1)] = np.inf
+        z = rows(3)
+        x[z] = lose * np.abs(x[z])                           # losers ...
+        zero = rng.random(x.shape) < 0.2                     # ... and zeros of both signs that win
+        zero[~z] = False
+        x[zero] = np.where(rng.random(int(zero.sum())) < 0.5, 0.0, -0.0)
+        want = np.empty((nseg, C_), np.float32)
+        for s_ in range(nseg):
+            acc = x[ptr[s_]].copy()
+            for r in range(ptr[s_] + 1, ptr[s_ + 1]):
+                take = x[r] > acc if mode == "max" else x[r] < acc
+                acc = np.where(take, x[r], acc)
+            want[s_] = acc
+        got = N(segment_csr(T(x), T(ptr), reduce=mode))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), C_
+        assert (np.signbit(want[kind == 3]) & (want[kind == 3] == 0)).any()      # -0.0 results are in
+
+
+@pytest.mark.parametrize("mode", ["max", "min"])
 def test_segment_csr_nan_rows_long_equals_short_kernel(mode):
     """Rows that hold a NaN: the in-order fold of the reference's segment reduction keeps a
     NaN only when it is the first row of a segment (every comparison with it is false), and
