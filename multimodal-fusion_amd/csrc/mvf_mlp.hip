@@ -1711,9 +1711,14 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
         for (int i = 0; i < SHORT; ++i)
             if (i < n) mx = (i == 0 || cs[i] > mx) ? cs[i] : mx;
     } else {
-        for (i64 r = a; r < b; ++r) {
-            const float c = comp[(size_t)r * G + g];
-            mx = (r == a || c > mx) ? c : mx;
+        // longer segments: SHORT rows per step, their loads in flight together (a loop of
+        // single dependent loads makes the few lanes with many views hold up the whole launch)
+        for (i64 r0 = a; r0 < b; r0 += SHORT) {
+#pragma unroll
+            for (int i = 0; i < SHORT; ++i) cs[i] = r0 + i < b ? comp[(size_t)(r0 + i) * G + g] : 0.f;
+#pragma unroll
+            for (int i = 0; i < SHORT; ++i)
+                if (r0 + i < b) mx = ((r0 == a && i == 0) || cs[i] > mx) ? cs[i] : mx;
         }
     }
     if (gate) {
@@ -1742,16 +1747,27 @@ __global__ __launch_bounds__(256) void attention_scores_kernel(
             if (i < n) att[(size_t)(a + i) * G + g] = __fmul_rn(__fdiv_rn(cs[i], sum), fold);
         return;
     }
-    for (i64 r = a; r < b; ++r) {
-        float c = __fsub_rn(comp[(size_t)r * G + g], mx);
-        if (group_scaling) c = __fdiv_rn(c, sq);
-        const float e = expf(c);
-        att[(size_t)r * G + g] = e;
-        sum = (r == a) ? e : __fadd_rn(sum, e);
+    for (i64 r0 = a; r0 < b; r0 += SHORT) {
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i) cs[i] = r0 + i < b ? comp[(size_t)(r0 + i) * G + g] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i)
+            if (r0 + i < b) {
+                float c = __fsub_rn(cs[i], mx);
+                if (group_scaling) c = __fdiv_rn(c, sq);
+                const float e = expf(c);
+                att[(size_t)(r0 + i) * G + g] = e;
+                sum = (r0 == a && i == 0) ? e : __fadd_rn(sum, e);
+            }
     }
     sum = __fadd_rn(sum, eps);
-    for (i64 r = a; r < b; ++r)
-        att[(size_t)r * G + g] = __fmul_rn(__fdiv_rn(att[(size_t)r * G + g], sum), fold);
+    for (i64 r0 = a; r0 < b; r0 += SHORT) {
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i) cs[i] = r0 + i < b ? att[(size_t)(r0 + i) * G + g] : 0.f;
+#pragma unroll
+        for (int i = 0; i < SHORT; ++i)
+            if (r0 + i < b) att[(size_t)(r0 + i) * G + g] = __fmul_rn(__fdiv_rn(cs[i], sum), fold);
+    }
 }
 
 // x_pool[s][c] = (sum_r x[r][c] * att[r][group(c)]) * gate[s][group(c)], rows
