@@ -73,3 +73,14 @@ for key, attr in (("C", "_last_C"), ("A", "_last_A"), ("G", "_last_G"), ("x_pool
 g = exact["G"]
 if g is not None:
     print("gate values: min %.3e median %.3e max %.3e" % (np.abs(g).min(), np.median(np.abs(g)), np.abs(g).max()))
+# the pool itself: the oracle's arithmetic on the fused path's own intermediates
+xm = mod._last_x_mod.cpu().numpy()
+A = mod._last_A.cpu().numpy().reshape(xm.shape[0], -1)
+ptr_np = np.asarray(a[3] if is_qkv else a[2], np.int64)
+G_ = mod.num_groups
+S = orc.segment_csr(xm * orc.expand_group_feat(A, G_, xm.shape[1]), ptr_np, "sum")
+if exact["G"] is not None:
+    S = S * orc.expand_group_feat(mod._last_G.cpu().numpy().reshape(S.shape[0], -1), G_, xm.shape[1])
+print("  pool of the fused intermediates in the oracle's arithmetic:", far(S, exact["x_pool"]),
+      "| fused pool against it:", far(got, S.astype(np.float64)))
+print("  x_mod fused", far(mod._last_x_mod, exact["x_mod"]), "| oracle", far(want["x_mod"], exact["x_mod"]) if "x_mod" in want else "")
